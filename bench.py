@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the stable-fluids hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--size 8192] [--iters 80]
+
+A "step" is ONE poisson_solve (zero fill + `iters` red-black SOR iterations, poisson.cpp:114-125)
+on a `size` x `size` fp32 grid held in HBM -- BASELINE.json's headline metric "cell-iters/sec (SOR
+sweep)", config[2] "8192x8192 fp32, 80 SOR iters/step" at N = 1 and config[3] (same grid, row-slab
+split with RCCL halo exchange) at N > 1, i.e. STRONG scaling.  After the timed region the full
+sim step (advect, divergence, solve, gradient, dye advect: ino:252-287) is timed separately and
+reported as `sim_steps_per_sec` (the metric's "+ steps/sec" half).
+
+Launch: N = 1 directly; N > 1 through `python -m torch.distributed.run --nproc-per-node N ...`,
+one process per GPU.  torch.distributed (gloo) carries only the bootstrap (RCCL unique id,
+barriers, max-over-ranks); every halo byte moves through RCCL send/recv issued by the C++
+library on the solver's own HIP stream.
+
+Output: ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      algorithmic bytes (16 B per cell-iteration) / avg kernel duration
+                measured with HIP events on the solver's stream, against the 8 TB/s HBM peak
+  cpu_baseline  the reference's own CPU loop (oracle/_ref, or the oracle port) on this host,
+                1 thread, bounded sample; N = 1 only
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+SOR_BYTES_PER_CELL_ITER = 16
+
+
+def synthetic_velocity(dim_x, row_begin, row_end, seed=12345, vamp=100.0):
+    """Seeded per-cell hash -> velocity in [-vamp, vamp]; independent of the slab split."""
+    j = np.arange(row_begin, row_end, dtype=np.uint64)[:, None]
+    i = np.arange(dim_x, dtype=np.uint64)[None, :]
+    out = np.empty((row_end - row_begin, dim_x, 2), np.float32)
+    for comp in (0, 1):
+        h = (j * np.uint64(dim_x) + i) * np.uint64(2) + np.uint64(comp) + np.uint64(seed) * np.uint64(0x9E3779B9)
+        h = (h * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(31)
+        h = (h * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        h ^= h >> np.uint64(29)
+        out[..., comp] = ((h >> np.uint64(40)) % np.uint64(2001)).astype(np.float32)
+    out -= 1000.0
+    out *= np.float32(vamp / 1000.0)
+    return out
+
+
+def synthetic_color(dim_x, row_begin, row_end, seed=777):
+    j = np.arange(row_begin, row_end, dtype=np.uint64)[:, None, None]
+    i = np.arange(dim_x, dtype=np.uint64)[None, :, None]
+    k = np.arange(3, dtype=np.uint64)[None, None, :]
+    h = ((j * np.uint64(dim_x) + i) * np.uint64(3) + k + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+    h ^= h >> np.uint64(32)
+    return ((h >> np.uint64(20)) & np.uint64(0x7FFFFFFF)).astype(np.uint32)   # raw < 2^31
+
+
+def cpu_baseline(size, budget_s=12.0):
+    """Reference CPU loop (1 thread) on a bounded sample of the same workload."""
+    from oracle import loader  # checker / baseline only
+    path = loader.reference() if loader.reference_available() else loader.port()
+    d = np.random.default_rng(5).standard_normal((size, size)).astype(np.float32) * np.float32(0.1)
+    t0 = time.perf_counter()
+    path.poisson_solve(d, 1.0, 2, np.float32(1.96))
+    probe = (time.perf_counter() - t0) / 2
+    iters = int(max(2, min(80, budget_s / max(probe, 1e-6))))
+    t0 = time.perf_counter()
+    path.poisson_solve(d, 1.0, iters, np.float32(1.96))
+    dt = time.perf_counter() - t0
+    return {"value": size * size * iters / dt, "unit": "cell-iters/s", "cores": 1,
+            "kind": path.kind,
+            "sample": f"poisson_solve {size}x{size} fp32, {iters} iters, 1 thread, {dt:.1f} s "
+                      f"({'unmodified reference sources' if path.kind == 'reference' else 'oracle C port'}, "
+                      f"g++/gcc -O2 -ffp-contract=off)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--iters", type=int, default=80)
+    ap.add_argument("--fuse", type=int, default=0, help="SOR half-sweeps fused per launch (0 = library default)")
+    ap.add_argument("--sor-kernel", type=int, default=0)
+    ap.add_argument("--sor-rows", type=int, default=0)
+    ap.add_argument("--sim-steps", type=int, default=3, help="full sim steps timed after the main region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE={world})")
+        args.gpus = world
+
+    # load the product library (system ROCm runtime) before torch pulls in its own copy
+    sfl = importlib.import_module("esp32-fluid-simulation_amd")
+    capi = sfl.capi
+    if sfl.device_count() < 1:
+        sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    size, iters = args.size, args.iters
+    s = sfl.Solver(size, size, device=local_rank, rank=rank, nranks=world)
+    if args.fuse:
+        s.set_option(capi.OPT_SOR_FUSE, args.fuse)
+    if args.sor_kernel:
+        s.set_option(capi.OPT_SOR_KERNEL, args.sor_kernel)
+    if args.sor_rows:
+        s.set_option(capi.OPT_SOR_ROWS, args.sor_rows)
+    if world > 1:
+        uid = [sfl.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        s.comm_attach(uid[0])
+
+    # synthetic inputs, resident in HBM before anything is timed
+    s.upload(capi.FIELD_VELOCITY, synthetic_velocity(size, s.row_begin, s.row_end))
+    s.upload(capi.FIELD_COLOR, synthetic_color(size, s.row_begin, s.row_end))
+    s.calculate_divergence(1.0)     # right-hand side = divergence of the velocity
+    s.synchronize()
+
+    def sync_all():
+        s.synchronize()
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+
+    omega = np.float32(1.96)
+    for _ in range(args.warmup):
+        s.poisson_solve(1.0, iters, omega)
+    sync_all()
+    barrier()
+    t0 = time.perf_counter()
+    s.timer_start()
+    for _ in range(args.steps):
+        s.poisson_solve(1.0, iters, omega)
+    ev_ms = s.timer_stop()
+    sync_all()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    info = s.last_solve_info()
+
+    if world > 1:
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+
+    # full sim step, timed separately (not part of `value`)
+    sim_sps = None
+    if args.sim_steps > 0:
+        dtf = np.float32(1 / 30.0)
+        s.step(dtf, 1.0, iters, omega)
+        sync_all()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.sim_steps):
+            s.step(dtf, 1.0, iters, omega)
+        sync_all()
+        barrier()
+        sim_t = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([sim_t], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sim_t = float(t[0])
+        sim_sps = args.sim_steps / sim_t
+
+    if rank == 0:
+        cells = size * size
+        value = cells * iters * args.steps / elapsed
+        launches = max(info["launches"], 1)
+        # dominant kernel: one launch relaxes every owned cell `fuse`/2 times
+        avg_launch_s = (ev_ms / 1e3) / (args.steps * launches)
+        bytes_per_launch = SOR_BYTES_PER_CELL_ITER * (cells / world) * iters / launches
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        name, cus, mem = sfl.device_info(local_rank)
+        out = {
+            "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"poisson_solve {size}x{size} fp32, {iters} red-black SOR iters/step, "
+                                   f"omega 1.96, dx 1, rhs = divergence of a seeded velocity field",
+                       "grid": [size, size], "iters": iters,
+                       "parallelism": "1 GPU" if world == 1 else f"row-slab x{world}, RCCL halo exchange",
+                       "sor_launches_per_solve": info["launches"],
+                       "halo_exchanges_per_solve": info["exchanges"],
+                       "half_sweeps_fused_per_launch": info["fuse"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
+                         "avg_launch_us": avg_launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "sim_steps_per_sec": sim_sps,
+            "device": name,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(size)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out), flush=True)
+
+    s.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+// kernels.h -- launch interface of the gfx950 kernels (internal; the public boundary is
+// include/sfl.h).  Every launcher is asynchronous on the given stream and returns the
+// hipError_t of the launch.
+//
+// Geometry.  A context stores each field as a LOCAL array of `lrows` rows of `dim_x`
+// elements; local row l holds GLOBAL row grow0 + l of a domain of gdim_y rows (a whole-domain
+// context has grow0 = 0, lrows = gdim_y; a slab has ghost rows on both sides, some of which
+// may lie outside the domain at the global top / bottom and are then never touched).
+// Row ranges passed to launchers are GLOBAL rows [g_begin, g_end), already clipped to the
+// domain by the caller.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfl {
+
+struct Slab {
+    int dim_x;   // row length (cells)
+    int gdim_y;  // rows of the global domain
+    int grow0;   // global row held by local row 0 (may be negative)
+    int lrows;   // rows allocated locally
+};
+
+// ---- advection (advect.h:24-85) ------------------------------------------------------
+// Output rows [g_begin, g_end).  `p` may be read on global rows [valid_begin, valid_end)
+// only; a back-trace that needs another row raises *halo_flag (device int, may be null on a
+// whole-domain context where every row is present).
+hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
+                               Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
+                               float dt, bool no_slip, int *halo_flag);
+hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
+                                  const float *vel, Slab g, int g_begin, int g_end,
+                                  int valid_begin, int valid_end, float dt, bool no_slip,
+                                  int *halo_flag);
+
+// ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
+hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
+                             int g_end, float two_dx_inv);
+hipError_t launch_subtract_gradient(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
+                                    int g_end, float two_dx_inv);
+
+// ---- red-black SOR (poisson.cpp:14-112) ------------------------------------------------
+struct SorParams {
+    float dx;
+    float omega;
+    float one_minus_omega;  // (1 - omega) evaluated in float on the host, poisson.cpp:98,111
+};
+
+// Baseline: ONE colour pass, in place, over global rows [g_begin, g_end).
+// colour 0 = even (i + j), the first pass of every iteration (poisson.cpp:22,57-60).
+hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g, int g_begin,
+                                 int g_end, int colour, SorParams prm);
+
+// Fused streaming kernel: `nsweeps` (even, 2..SFL_MAX_FUSE) consecutive colour passes,
+// starting with `first_colour`, in ONE launch.  Reads p_in (or nothing when p_in == nullptr:
+// p is then implicitly zero, the fused zero-fill of poisson.cpp:117-119) and d, writes the
+// result for global rows [g_begin, g_end) to p_out (p_out must not alias p_in).  Needs p_in
+// valid on rows [g_begin - nsweeps, g_end + nsweeps) and d on one row less each side, clipped
+// to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).
+#define SFL_MAX_FUSE 16
+hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
+                            Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
+                            SorParams prm, int rows_per_chunk);
+
+// Fill rows [g_begin, g_end) of a float field with zero (poisson.cpp:117-119).
+hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_end);
+
+// Point forces (ino:264-269): velocity[cell] = vel for n (cell, vel) pairs whose row lies in
+// [g_begin, g_end).  cells = {i, j} pairs (global), device arrays.
+hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
+                               const int *cells_ij, const float *vel_xy, int n);
+
+}  // namespace sfl

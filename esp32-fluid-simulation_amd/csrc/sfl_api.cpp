@@ -1,0 +1,894 @@
+// sfl_api.cpp -- the C ABI of include/sfl.h: contexts (one GPU's row slab, fields resident in
+// HBM), operator entry points, the executor that walks slab_plan.h programs, RCCL halo
+// exchange, and the host-pointer drop-ins.  Host C++ only; the kernels live in
+// stencil_kernels.hip / sor_fused.hip.
+//
+// There is deliberately no CPU compute path in this file: every operator ends in a kernel
+// launch, and fails with SFL_ERR_HIP when no device is usable.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sfl.h"
+#include "kernels.h"
+#include "slab_plan.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? SFL_ERR_NOMEM : SFL_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                        __LINE__);                                                         \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                    \
+    do {                                                                                  \
+        ncclResult_t r_ = (expr);                                                         \
+        if (r_ != ncclSuccess)                                                            \
+            return fail(SFL_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define SFL_TRY(expr)          \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != SFL_OK) return rc_; \
+    } while (0)
+
+constexpr int kGhostRows = 32;  // ghost rows allocated per side on a slab (nranks > 1)
+
+size_t field_elem_bytes(int field)
+{
+    switch (field) {
+        case SFL_FIELD_VELOCITY: return 8;
+        case SFL_FIELD_COLOR: return 12;
+        case SFL_FIELD_DIVERGENCE:
+        case SFL_FIELD_PRESSURE: return 4;
+    }
+    return 0;
+}
+
+struct Group;
+
+}  // namespace
+
+struct sfl_context {
+    int device = 0;
+    int dim_x = 0, gdim_y = 0;
+    int rank = 0, nranks = 1;
+    int g0 = 0, g1 = 0;  // owned global rows
+    int ghost = 0;       // ghost rows per side
+    sfl::Slab geom{};
+    hipStream_t stream = nullptr;
+    bool owns_stream = true;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+
+    // fields: local arrays of geom.lrows rows (allocated on first use)
+    float *vel = nullptr, *vel_tmp = nullptr;
+    uint32_t *col = nullptr, *col_tmp = nullptr;
+    float *div = nullptr;
+    float *p = nullptr, *p_alt = nullptr;  // p = current pressure, p_alt = ping-pong partner
+    int *halo_flag = nullptr;
+
+    // queued point forces (ino:264-269)
+    std::vector<int> force_cells;
+    std::vector<float> force_vel;
+    int *d_force_cells = nullptr;
+    float *d_force_vel = nullptr;
+    int d_force_cap = 0;
+
+    int opt_sor_kernel = 0, opt_sor_fuse = 8, opt_advect_halo = 4, opt_sor_rows = 0,
+        opt_transport = 0;
+
+    ncclComm_t comm = nullptr;
+    std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
+    std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
+
+    int last_launches = 0, last_exchanges = 0, last_fuse = 0;
+
+    size_t local_cells() const { return (size_t)geom.lrows * dim_x; }
+    size_t owned_offset_cells() const { return (size_t)ghost * dim_x; }
+};
+
+namespace {
+
+// In-process virtual ranks: slabs of one domain living on ONE device, ordered by one stream.
+struct Group {
+    std::vector<sfl_context *> members;
+    hipStream_t stream = nullptr;
+    ~Group() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+int use_device(sfl_context *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return SFL_OK;
+}
+
+template <class T>
+int ensure(sfl_context *c, T *&ptr, size_t elem_bytes, bool zero)
+{
+    if (ptr) return SFL_OK;
+    SFL_TRY(use_device(c));
+    void *m = nullptr;
+    const size_t bytes = c->local_cells() * elem_bytes;
+    HIP_TRY(hipMalloc(&m, bytes));
+    if (zero) HIP_TRY(hipMemsetAsync(m, 0, bytes, c->stream));
+    ptr = static_cast<T *>(m);
+    return SFL_OK;
+}
+
+int ensure_field(sfl_context *c, int field)
+{
+    switch (field) {
+        case SFL_FIELD_VELOCITY: return ensure(c, c->vel, 8, true);
+        case SFL_FIELD_COLOR: return ensure(c, c->col, 12, true);
+        case SFL_FIELD_DIVERGENCE: return ensure(c, c->div, 4, true);
+        case SFL_FIELD_PRESSURE: return ensure(c, c->p, 4, true);
+    }
+    return fail(SFL_ERR_INVALID, "unknown field id %d", field);
+}
+
+void *field_ptr(sfl_context *c, int field)
+{
+    switch (field) {
+        case SFL_FIELD_VELOCITY: return c->vel;
+        case SFL_FIELD_COLOR: return c->col;
+        case SFL_FIELD_DIVERGENCE: return c->div;
+        case SFL_FIELD_PRESSURE: return c->p;
+    }
+    return nullptr;
+}
+
+std::vector<sfl_context *> peers_of(sfl_context *c)
+{
+    if (c->group) return c->group->members;
+    return {c};
+}
+
+int min_owned_rows(const sfl_context *c)
+{
+    int m = c->gdim_y;
+    for (int r = 0; r < c->nranks; ++r) {
+        int b, e;
+        sfl::slab_rows(c->gdim_y, c->nranks, r, &b, &e);
+        if (e - b < m) m = e - b;
+    }
+    return m;
+}
+
+// ---- halo exchange ---------------------------------------------------------------------
+// Every rank sends its `rows` lowest owned rows down and its `rows` highest owned rows up, and
+// receives the neighbours' into the ghost rows adjacent to its owned block.
+int exchange(const std::vector<sfl_context *> &peers, int field, int rows)
+{
+    if (rows <= 0) return SFL_OK;
+    sfl_context *any = peers[0];
+    if (any->nranks == 1) return SFL_OK;
+    if (rows > any->ghost)
+        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the %d ghost rows of a slab", rows,
+                    any->ghost);
+    if (rows > min_owned_rows(any))
+        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the thinnest slab (%d rows)", rows,
+                    min_owned_rows(any));
+    const size_t eb = field_elem_bytes(field);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, field));
+        ++c->last_exchanges;
+    }
+    const size_t row_bytes = (size_t)any->dim_x * eb;
+    const size_t bytes = row_bytes * rows;
+    auto row_ptr = [&](sfl_context *c, int g) {
+        return static_cast<char *>(field_ptr(c, field)) + (size_t)(g - c->geom.grow0) * row_bytes;
+    };
+
+    if (any->group) {  // in-process transport: all virtual ranks share one stream
+        for (sfl_context *c : peers) {
+            SFL_TRY(use_device(c));
+            if (c->rank > 0) {
+                sfl_context *lo = peers[c->rank - 1];
+                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - rows), row_ptr(lo, lo->g1 - rows), bytes,
+                                       hipMemcpyDeviceToDevice, c->stream));
+            }
+            if (c->rank < c->nranks - 1) {
+                sfl_context *hi = peers[c->rank + 1];
+                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1), row_ptr(hi, hi->g0), bytes,
+                                       hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        return SFL_OK;
+    }
+
+    sfl_context *c = any;
+    if (!c->comm)
+        return fail(SFL_ERR_STATE, "slab %d/%d has no communicator: call sfl_comm_attach() or "
+                    "sfl_group_link() first", c->rank, c->nranks);
+    SFL_TRY(use_device(c));
+    NCCL_TRY(ncclGroupStart());
+    if (c->rank > 0) {
+        NCCL_TRY(ncclSend(row_ptr(c, c->g0), bytes, ncclChar, c->rank - 1, c->comm, c->stream));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g0 - rows), bytes, ncclChar, c->rank - 1, c->comm,
+                          c->stream));
+    }
+    if (c->rank < c->nranks - 1) {
+        NCCL_TRY(ncclSend(row_ptr(c, c->g1 - rows), bytes, ncclChar, c->rank + 1, c->comm,
+                          c->stream));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g1), bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return SFL_OK;
+}
+
+int clip_lo(const sfl_context *c, int g) { return g < 0 ? 0 : g; }
+int clip_hi(const sfl_context *c, int g) { return g > c->gdim_y ? c->gdim_y : g; }
+
+sfl::SorParams sor_params(float dx, float omega)
+{
+    sfl::SorParams prm;
+    prm.dx = dx;
+    prm.omega = omega;
+    prm.one_minus_omega = 1.0f - omega;  // (1 - omega) in float, poisson.cpp:98,111
+    return prm;
+}
+
+int effective_fuse(const sfl_context *c)
+{
+    int f = c->opt_sor_fuse;
+    if (f < 2) f = 2;
+    if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
+    return f & ~1;
+}
+
+int effective_kernel(const sfl_context *c) { return c->opt_sor_kernel == 1 ? 1 : 2; }
+
+// ---- poisson_solve executor --------------------------------------------------------------
+int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm)
+{
+    SFL_TRY(use_device(c));
+    if (st.kind == SFL_STEP_ZERO) {
+        HIP_TRY(sfl::launch_zero_rows(c->stream, c->p, c->geom, clip_lo(c, c->geom.grow0),
+                                      clip_hi(c, c->geom.grow0 + c->geom.lrows)));
+        ++c->last_launches;
+        return SFL_OK;
+    }
+    if (st.nsweeps == 1) {
+        HIP_TRY(sfl::launch_sor_half_sweep(c->stream, c->p, c->div, c->geom, st.g_begin, st.g_end,
+                                           st.first_colour, prm));
+        ++c->last_launches;
+        return SFL_OK;
+    }
+    SFL_TRY(ensure(c, c->p_alt, 4, false));
+    HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
+                                  c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
+                                  c->opt_sor_rows));
+    std::swap(c->p, c->p_alt);
+    ++c->last_launches;
+    return SFL_OK;
+}
+
+int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
+{
+    if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
+    std::vector<std::vector<sfl_plan_step>> progs;
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel));
+        c->last_launches = c->last_exchanges = 0;
+        c->last_fuse = kernel == 1 ? 1 : fuse;
+    }
+    const sfl::SorParams prm = sor_params(dx, omega);
+    if (iters == 0) {  // the reference still zero-fills p (poisson.cpp:117-119)
+        for (sfl_context *c : peers) {
+            SFL_TRY(use_device(c));
+            HIP_TRY(sfl::launch_zero_rows(c->stream, c->p, c->geom, c->g0, c->g1));
+        }
+        return SFL_OK;
+    }
+    for (size_t i = 0; i < progs[0].size(); ++i) {
+        const sfl_plan_step &st0 = progs[0][i];
+        if (st0.kind == SFL_STEP_EXCHANGE) {
+            SFL_TRY(exchange(peers, st0.field, st0.rows));
+        } else {
+            for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+        }
+    }
+    return SFL_OK;
+}
+
+int check_dims(int dim_x, int dim_y)
+{
+    // with a dimension of 1 the reference's edge loops revisit cells: rejected
+    if (dim_x < 2 || dim_y < 2)
+        return fail(SFL_ERR_INVALID, "dim_x and dim_y must be >= 2 (got %d x %d)", dim_x, dim_y);
+    if ((int64_t)dim_x * dim_y > (int64_t)1 << 30)
+        return fail(SFL_ERR_INVALID, "domain of %d x %d cells exceeds the int index range of "
+                    "operations.h:7", dim_x, dim_y);
+    return SFL_OK;
+}
+
+int default_device()
+{
+    const char *e = getenv("SFL_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+// RAII helper for the host-pointer drop-ins
+struct TempCtx {
+    sfl_context *c = nullptr;
+    ~TempCtx() { if (c) sfl_destroy(c); }
+};
+
+int upload_raw(sfl_context *c, void *dev, const void *host, size_t elem_bytes)
+{
+    SFL_TRY(use_device(c));
+    const size_t bytes = (size_t)(c->g1 - c->g0) * c->dim_x * elem_bytes;
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(dev) + c->owned_offset_cells() * elem_bytes, host,
+                           bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SFL_OK;
+}
+
+int download_raw(sfl_context *c, const void *dev, void *host, size_t elem_bytes)
+{
+    SFL_TRY(use_device(c));
+    const size_t bytes = (size_t)(c->g1 - c->g0) * c->dim_x * elem_bytes;
+    HIP_TRY(hipMemcpyAsync(host, static_cast<const char *>(dev) + c->owned_offset_cells() * elem_bytes,
+                           bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SFL_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// utilities
+// ==========================================================================================
+extern "C" {
+
+int sfl_abi_version(void) { return SFL_ABI_VERSION; }
+
+const char *sfl_last_error(void) { return g_error.c_str(); }
+
+int sfl_device_count(int *count)
+{
+    if (!count) return fail(SFL_ERR_INVALID, "count is NULL");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SFL_ERR_HIP, "no usable HIP device: %s", hipGetErrorString(e));
+    *count = n;
+    return SFL_OK;
+}
+
+int sfl_device_info(int device, char *name, size_t name_cap, int *compute_units,
+                    size_t *total_mem_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_cap) {
+        snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+    return SFL_OK;
+}
+
+int sfl_slab_rows(int dim_y, int nranks, int rank, int *row_begin, int *row_end)
+{
+    if (dim_y < 1 || nranks < 1 || rank < 0 || rank >= nranks || !row_begin || !row_end)
+        return fail(SFL_ERR_INVALID, "bad slab query (dim_y %d, rank %d of %d)", dim_y, rank, nranks);
+    sfl::slab_rows(dim_y, nranks, rank, row_begin, row_end);
+    return SFL_OK;
+}
+
+int sfl_sor_pass_plan(int iters, int fuse, int *n_passes, int *passes, int cap)
+{
+    if (iters < 0 || fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE || !n_passes)
+        return fail(SFL_ERR_INVALID, "bad pass plan query (iters %d, fuse %d)", iters, fuse);
+    const std::vector<int> v = sfl::sor_pass_plan(iters, fuse);
+    *n_passes = (int)v.size();
+    if (passes)
+        for (int k = 0; k < (int)v.size() && k < cap; ++k) passes[k] = v[k];
+    return SFL_OK;
+}
+
+int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
+                     sfl_plan_step *steps, int cap, int *n_steps)
+{
+    if (dim_y < 2 || nranks < 1 || rank < 0 || rank >= nranks || iters < 0 || !n_steps ||
+        (kernel != 1 && kernel != 2) || (kernel == 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
+        return fail(SFL_ERR_INVALID, "bad plan query");
+    const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel);
+    *n_steps = (int)v.size();
+    if (steps)
+        for (int k = 0; k < (int)v.size() && k < cap; ++k) steps[k] = v[k];
+    return SFL_OK;
+}
+
+// ==========================================================================================
+// contexts
+// ==========================================================================================
+int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int rank, int nranks)
+{
+    if (!out) return fail(SFL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    SFL_TRY(check_dims(dim_x, dim_y));
+    if (nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(SFL_ERR_INVALID, "bad rank %d of %d", rank, nranks);
+    if (nranks > dim_y) return fail(SFL_ERR_INVALID, "more slabs (%d) than rows (%d)", nranks, dim_y);
+    int ndev = 0;
+    SFL_TRY(sfl_device_count(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(SFL_ERR_HIP, "device %d not available (%d visible)", device, ndev);
+
+    std::unique_ptr<sfl_context> c(new sfl_context);
+    c->device = device;
+    c->dim_x = dim_x;
+    c->gdim_y = dim_y;
+    c->rank = rank;
+    c->nranks = nranks;
+    sfl::slab_rows(dim_y, nranks, rank, &c->g0, &c->g1);
+    c->ghost = nranks > 1 ? kGhostRows : 0;
+    c->geom.dim_x = dim_x;
+    c->geom.gdim_y = dim_y;
+    c->geom.grow0 = c->g0 - c->ghost;
+    c->geom.lrows = (c->g1 - c->g0) + 2 * c->ghost;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    void *flag = nullptr;
+    HIP_TRY(hipMalloc(&flag, sizeof(int)));
+    HIP_TRY(hipMemset(flag, 0, sizeof(int)));
+    c->halo_flag = static_cast<int *>(flag);
+    *out = c.release();
+    return SFL_OK;
+}
+
+int sfl_create(sfl_context **out, int device, int dim_x, int dim_y)
+{
+    return sfl_create_slab(out, device, dim_x, dim_y, 0, 1);
+}
+
+int sfl_destroy(sfl_context *c)
+{
+    if (!c) return SFL_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->group) {
+        // dissolve the group: the remaining members become plain slabs without a transport
+        // (their collective operators then fail with SFL_ERR_STATE); the shared stream lives
+        // on through `keepalive` until the last member is destroyed
+        std::shared_ptr<Group> g = c->group;
+        for (sfl_context *m : g->members) m->group.reset();
+    }
+    c->keepalive.reset();
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
+                    (void *)c->div, (void *)c->p, (void *)c->p_alt, (void *)c->halo_flag,
+                    (void *)c->d_force_cells, (void *)c->d_force_vel})
+        if (m) (void)hipFree(m);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SFL_OK;
+}
+
+int sfl_set_option(sfl_context *c, int option, int value)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    switch (option) {
+        case SFL_OPT_SOR_KERNEL:
+            if (value < 0 || value > 2) return fail(SFL_ERR_INVALID, "SOR kernel must be 0, 1 or 2");
+            c->opt_sor_kernel = value;
+            return SFL_OK;
+        case SFL_OPT_SOR_FUSE:
+            if (value < 2 || value > SFL_MAX_FUSE || (value & 1))
+                return fail(SFL_ERR_INVALID, "fuse must be even, 2..%d (got %d)", SFL_MAX_FUSE, value);
+            c->opt_sor_fuse = value;
+            return SFL_OK;
+        case SFL_OPT_ADVECT_HALO:
+            if (value < 1 || value > kGhostRows)
+                return fail(SFL_ERR_INVALID, "advect halo must be 1..%d rows", kGhostRows);
+            c->opt_advect_halo = value;
+            return SFL_OK;
+        case SFL_OPT_SOR_ROWS:
+            if (value < 0) return fail(SFL_ERR_INVALID, "rows per chunk must be >= 0");
+            c->opt_sor_rows = value;
+            return SFL_OK;
+        case SFL_OPT_TRANSPORT:
+            c->opt_transport = value;
+            return SFL_OK;
+    }
+    return fail(SFL_ERR_INVALID, "unknown option %d", option);
+}
+
+int sfl_get_option(sfl_context *c, int option, int *value)
+{
+    if (!c || !value) return fail(SFL_ERR_INVALID, "NULL argument");
+    switch (option) {
+        case SFL_OPT_SOR_KERNEL: *value = c->opt_sor_kernel; return SFL_OK;
+        case SFL_OPT_SOR_FUSE: *value = c->opt_sor_fuse; return SFL_OK;
+        case SFL_OPT_ADVECT_HALO: *value = c->opt_advect_halo; return SFL_OK;
+        case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
+        case SFL_OPT_TRANSPORT: *value = c->opt_transport; return SFL_OK;
+    }
+    return fail(SFL_ERR_INVALID, "unknown option %d", option);
+}
+
+int sfl_slab_of(sfl_context *c, int *row_begin, int *row_end, int *rank, int *nranks)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (row_begin) *row_begin = c->g0;
+    if (row_end) *row_end = c->g1;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return SFL_OK;
+}
+
+int sfl_comm_unique_id(void *id_out, size_t id_bytes)
+{
+    if (!id_out || id_bytes < sizeof(ncclUniqueId))
+        return fail(SFL_ERR_INVALID, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return SFL_OK;
+}
+
+int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
+{
+    if (!c || !id || id_bytes < sizeof(ncclUniqueId)) return fail(SFL_ERR_INVALID, "bad arguments");
+    if (c->comm || c->group) return fail(SFL_ERR_STATE, "context already has a transport");
+    SFL_TRY(use_device(c));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(ncclCommInitRank(&c->comm, c->nranks, uid, c->rank));
+    return SFL_OK;
+}
+
+int sfl_group_link(sfl_context **ctxs, int n)
+{
+    if (!ctxs || n < 1) return fail(SFL_ERR_INVALID, "bad group");
+    for (int r = 0; r < n; ++r) {
+        sfl_context *c = ctxs[r];
+        if (!c || c->nranks != n || c->rank != r || c->device != ctxs[0]->device ||
+            c->dim_x != ctxs[0]->dim_x || c->gdim_y != ctxs[0]->gdim_y || c->comm || c->group)
+            return fail(SFL_ERR_INVALID, "ctxs[%d] is not slab %d of %d on the group's device", r, r, n);
+    }
+    auto g = std::make_shared<Group>();
+    g->members.assign(ctxs, ctxs + n);
+    HIP_TRY(hipSetDevice(ctxs[0]->device));
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    for (int r = 0; r < n; ++r) {  // one stream orders the whole group
+        sfl_context *c = ctxs[r];
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+        c->stream = g->stream;
+        c->owns_stream = false;
+        c->group = g;
+        c->keepalive = g;
+    }
+    return SFL_OK;
+}
+
+int sfl_upload(sfl_context *c, int field, const void *host, size_t bytes)
+{
+    if (!c || !host) return fail(SFL_ERR_INVALID, "NULL argument");
+    const size_t eb = field_elem_bytes(field);
+    if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
+    const size_t want = (size_t)(c->g1 - c->g0) * c->dim_x * eb;
+    if (bytes != want) return fail(SFL_ERR_INVALID, "field %d: got %zu bytes, slab holds %zu", field, bytes, want);
+    SFL_TRY(ensure_field(c, field));
+    return upload_raw(c, field_ptr(c, field), host, eb);
+}
+
+int sfl_download(sfl_context *c, int field, void *host, size_t bytes)
+{
+    if (!c || !host) return fail(SFL_ERR_INVALID, "NULL argument");
+    const size_t eb = field_elem_bytes(field);
+    if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
+    const size_t want = (size_t)(c->g1 - c->g0) * c->dim_x * eb;
+    if (bytes != want) return fail(SFL_ERR_INVALID, "field %d: got %zu bytes, slab holds %zu", field, bytes, want);
+    SFL_TRY(ensure_field(c, field));
+    return download_raw(c, field_ptr(c, field), host, eb);
+}
+
+int sfl_field_device_ptr(sfl_context *c, int field, void **dev_ptr)
+{
+    if (!c || !dev_ptr) return fail(SFL_ERR_INVALID, "NULL argument");
+    const size_t eb = field_elem_bytes(field);
+    if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
+    SFL_TRY(ensure_field(c, field));
+    *dev_ptr = static_cast<char *>(field_ptr(c, field)) + c->owned_offset_cells() * eb;
+    return SFL_OK;
+}
+
+// ---- operators ---------------------------------------------------------------------------
+int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    }
+    SFL_TRY(exchange(peers, SFL_FIELD_VELOCITY, ctx->opt_advect_halo));
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
+        HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
+                                         clip_lo(c, c->g0 - h), clip_hi(c, c->g1 + h), dt,
+                                         no_slip != 0, c->nranks > 1 ? c->halo_flag : nullptr));
+        std::swap(c->vel, c->vel_tmp);  // ino:255
+    }
+    return SFL_OK;
+}
+
+int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+        SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    }
+    SFL_TRY(exchange(peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
+        HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, c->col, c->vel, c->geom, c->g0,
+                                            c->g1, clip_lo(c, c->g0 - h), clip_hi(c, c->g1 + h), dt,
+                                            no_slip != 0, c->nranks > 1 ? c->halo_flag : nullptr));
+        std::swap(c->col, c->col_tmp);  // ino:286
+    }
+    return SFL_OK;
+}
+
+int sfl_calculate_divergence(sfl_context *ctx, float dx)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+    }
+    SFL_TRY(exchange(peers, SFL_FIELD_VELOCITY, 1));
+    const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(sfl::launch_divergence(c->stream, c->div, c->vel, c->geom, c->g0, c->g1, two_dx_inv));
+    }
+    return SFL_OK;
+}
+
+int sfl_poisson_solve(sfl_context *ctx, float dx, int iters, float omega)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    return run_poisson(ctx, dx, iters, omega);
+}
+
+int sfl_subtract_gradient(sfl_context *ctx, float dx)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+    }
+    SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, 1));
+    const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(sfl::launch_subtract_gradient(c->stream, c->vel, c->p, c->geom, c->g0, c->g1,
+                                              two_dx_inv));
+    }
+    return SFL_OK;
+}
+
+int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && (!cells_ij || !vel_xy))) return fail(SFL_ERR_INVALID, "bad arguments");
+    for (sfl_context *c : peers_of(ctx)) {
+        c->force_cells.insert(c->force_cells.end(), cells_ij, cells_ij + 2 * n);
+        c->force_vel.insert(c->force_vel.end(), vel_xy, vel_xy + 2 * n);
+    }
+    return SFL_OK;
+}
+
+static int apply_queued_forces(sfl_context *c)
+{
+    const int n = (int)(c->force_cells.size() / 2);
+    if (n == 0) return SFL_OK;
+    SFL_TRY(use_device(c));
+    if (n > c->d_force_cap) {
+        if (c->d_force_cells) (void)hipFree(c->d_force_cells);
+        if (c->d_force_vel) (void)hipFree(c->d_force_vel);
+        c->d_force_cells = nullptr;
+        c->d_force_vel = nullptr;
+        void *a = nullptr, *b = nullptr;
+        HIP_TRY(hipMalloc(&a, sizeof(int) * 2 * n));
+        HIP_TRY(hipMalloc(&b, sizeof(float) * 2 * n));
+        c->d_force_cells = static_cast<int *>(a);
+        c->d_force_vel = static_cast<float *>(b);
+        c->d_force_cap = n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_force_cells, c->force_cells.data(), sizeof(int) * 2 * n,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_force_vel, c->force_vel.data(), sizeof(float) * 2 * n,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
+                                     c->d_force_vel, n));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors are about to be cleared
+    c->force_cells.clear();
+    c->force_vel.clear();
+    return SFL_OK;
+}
+
+int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(sfl_advect_velocity(ctx, dt, 1));              // ino:252-256
+    for (sfl_context *c : peers_of(ctx)) SFL_TRY(apply_queued_forces(c));  // ino:264-269
+    SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
+    SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));     // ino:275
+    SFL_TRY(sfl_subtract_gradient(ctx, dx));               // ino:276
+    SFL_TRY(sfl_advect_color(ctx, dt, 0));                 // ino:281-287
+    return SFL_OK;
+}
+
+int sfl_synchronize(sfl_context *ctx)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    int rc = SFL_OK;
+    for (sfl_context *c : peers_of(ctx)) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->nranks > 1) {
+            int flag = 0;
+            HIP_TRY(hipMemcpy(&flag, c->halo_flag, sizeof flag, hipMemcpyDeviceToHost));
+            if (flag) {
+                HIP_TRY(hipMemset(c->halo_flag, 0, sizeof flag));
+                rc = fail(SFL_ERR_HALO, "slab %d/%d: a back-trace left the %d-row advect halo; raise "
+                          "SFL_OPT_ADVECT_HALO", c->rank, c->nranks, c->opt_advect_halo);
+            }
+        }
+    }
+    return rc;
+}
+
+int sfl_timer_start(sfl_context *c)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(use_device(c));
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    return SFL_OK;
+}
+
+int sfl_timer_stop(sfl_context *c, float *elapsed_ms)
+{
+    if (!c || !elapsed_ms) return fail(SFL_ERR_INVALID, "NULL argument");
+    SFL_TRY(use_device(c));
+    HIP_TRY(hipEventRecord(c->ev_stop, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_stop));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev_start, c->ev_stop));
+    return SFL_OK;
+}
+
+int sfl_last_solve_info(sfl_context *c, int *launches, int *exchanges, int *fuse)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (launches) *launches = c->last_launches;
+    if (exchanges) *exchanges = c->last_exchanges;
+    if (fuse) *fuse = c->last_fuse;
+    return SFL_OK;
+}
+
+// ==========================================================================================
+// host-pointer drop-ins
+// ==========================================================================================
+int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int dim_x, int dim_y,
+                          float dt, int no_slip)
+{
+    if (!next_p || !p || !vel) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    if (next_p == p) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
+    TempCtx t;
+    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    sfl_context *c = t.c;
+    SFL_TRY(ensure(c, c->vel, 8, false));
+    SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    SFL_TRY(upload_raw(c, c->vel, vel, 8));
+    float *src = c->vel;
+    float *other = nullptr;
+    if (p != vel) {  // advected field differs from the velocity
+        SFL_TRY(ensure(c, other, 8, false));
+        SFL_TRY(upload_raw(c, other, p, 8));
+        src = other;
+    }
+    hipError_t e = sfl::launch_advect_vec2f(c->stream, c->vel_tmp, src, c->vel, c->geom, 0, dim_y, 0,
+                                            dim_y, dt, no_slip != 0, nullptr);
+    int rc = e == hipSuccess ? download_raw(c, c->vel_tmp, next_p, 8)
+                             : fail(SFL_ERR_HIP, "advect launch failed: %s", hipGetErrorString(e));
+    if (other) (void)hipFree(other);
+    return rc;
+}
+
+int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *vel, int dim_x,
+                             int dim_y, float dt, int no_slip)
+{
+    if (!next_p || !p || !vel) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    if (next_p == p) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
+    TempCtx t;
+    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, vel, (size_t)dim_x * dim_y * 8));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_COLOR, p, (size_t)dim_x * dim_y * 12));
+    SFL_TRY(sfl_advect_color(t.c, dt, no_slip));
+    return sfl_download(t.c, SFL_FIELD_COLOR, next_p, (size_t)dim_x * dim_y * 12);
+}
+
+int sfl_host_calculate_divergence(float *div, const float *v, int dim_x, int dim_y, float dx)
+{
+    if (!div || !v) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    TempCtx t;
+    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8));
+    SFL_TRY(sfl_calculate_divergence(t.c, dx));
+    return sfl_download(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4);
+}
+
+int sfl_host_subtract_gradient(float *v, const float *p, int dim_x, int dim_y, float dx)
+{
+    if (!v || !p) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    TempCtx t;
+    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4));
+    SFL_TRY(sfl_subtract_gradient(t.c, dx));
+    return sfl_download(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8);
+}
+
+int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, float dx, int iters,
+                           float omega)
+{
+    if (!p || !div) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    TempCtx t;
+    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    const char *k = getenv("SFL_SOR_KERNEL");
+    if (k) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_KERNEL, atoi(k)));
+    const char *f = getenv("SFL_SOR_FUSE");
+    if (f) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_FUSE, atoi(f)));
+    SFL_TRY(sfl_upload(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4));
+    SFL_TRY(sfl_poisson_solve(t.c, dx, iters, omega));
+    return sfl_download(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4);
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// sor_stream_core.h -- the fused red-black SOR pipeline, written once against a small
+// "wave backend" so that the SAME code runs (a) on gfx950, one 64-lane wavefront per tile
+// with V = float in VGPRs (sor_fused.hip), and (b) lane-by-lane on a CPU in the test
+// harness with V = 64 floats (tests/cpp/sor_stream_emu.cpp), where it is checked against
+// the oracle without a GPU.
+//
+// What it computes: NS consecutive colour passes (NS even: NS/2 full iterations of
+// poisson.cpp:121-124, even (i+j) first) of the in-place red-black SOR of
+// poisson.cpp:14-112 on one tile, in ONE sweep over the tile's rows, reading p and d once
+// and writing p once.  Bit-identical to running the passes one after the other.
+//
+// Tile = 128 columns (2 per lane: cell `a` at an even column x_a, cell `b` at x_a + 1)
+// x a run of rows streamed bottom-up.  Colours: a cell is "E" when (column + row) is even
+// (updated by the first pass of an iteration, poisson.cpp:22) and "O" otherwise.  In a row of
+// even parity the E cell of a lane is `a`, in an odd row it is `b`.
+//
+// Dependencies (5-point stencil, neighbours always have the other colour):
+//   E_m[r] = relax(E_{m-1}[r]; W/E from O_{m-1}[r]; S = O_{m-1}[r-1]; N = O_{m-1}[r+1]; d_E[r])
+//   O_m[r] = relax(O_{m-1}[r]; W/E from E_m[r];     S = E_m[r-1];     N = E_m[r+1];     d_O[r])
+// for version m = 1 .. NS/2 (version 0 = the loaded data).  Software pipeline: in the
+// iteration that receives input row y it computes E_m[y-(2m-1)] and O_m[y-2m] for every m, so
+// the finished row y-NS leaves the pipeline NS iterations after it entered.  Every value is
+// used for at most three iterations, hence three register slots per (colour, version),
+// addressed by (row mod 3); the loop is unrolled by 6 (= lcm of slot period 3 and row parity
+// 2) so that every slot and parity is a compile-time constant.  The right-hand side d of a row
+// is needed NS iterations long; it waits in a per-lane ring in LDS (nobody else reads it).
+//
+// Validity: a tile is loaded with NS extra columns / rows on every side; pass s of the NS
+// spoils one more ring of cells, the tile's interior [NS from each loaded edge] is exact.
+// Cells outside the domain hold -0.0f, the additive identity (x + -0.0f == x bitwise for
+// every x), so perimeter cells can add "absent" neighbours unconditionally:
+//   interior  sum = ((W + E) + S) + N                    poisson.cpp:107  (pois_sor_fast)
+//   perimeter sum = ((((+0 + W') + E') + S') + N'        poisson.cpp:69-86 (pois_gs_safe)
+// and both are evaluated as (((z + W) + E) + S) + N with z = -0.0f / +0.0f.
+#pragma once
+
+#if defined(__HIPCC__)
+#define SFL_HD __host__ __device__ __forceinline__
+#else
+#define SFL_HD inline
+#endif
+
+namespace sfl {
+namespace sor {
+
+constexpr int kUnroll = 6;       // iterations per unrolled loop body
+constexpr int kPrefetch = 6;     // rows in flight ahead of the pipeline (== kUnroll)
+constexpr int kTileCols = 128;   // columns per wave tile (2 per lane)
+
+constexpr int wrap3(int x) { return ((x % 3) + 3) % 3; }
+constexpr bool is_even(int x) { return ((x % 2) + 2) % 2 == 0; }
+constexpr int ring_rows(int ns) { return ns + 1; }  // rows of d alive at once
+
+// Per-lane facts used only by tiles that touch the domain boundary.
+template <class B>
+struct EdgeCell {
+    typename B::M in;       // column inside [0, dim_x)
+    typename B::V k_full;   // -1/n for a row with both vertical neighbours (n = 2 + #horizontal)
+    typename B::V k_part;   // -1/n for the bottom / top row            (n = 1 + #horizontal)
+    typename B::V z_full;   // +0 when the column is a wall column, else -0 (rows with both
+                            // vertical neighbours); bottom / top rows always use +0
+};
+
+struct RowFacts {  // wave-uniform
+    bool in_dom;   // 0 <= r < gdim_y
+    bool full;     // 0 < r < gdim_y - 1
+};
+
+template <class B>
+struct Consts {
+    typename B::V dx, omega, one_minus_omega;
+};
+
+template <class B, int NS>
+struct Pipe {
+    using V = typename B::V;
+    V E[NS / 2 + 1][3];
+    V O[NS / 2 + 1][3];             // O[NS/2] is never stored (written straight to memory)
+    V pa[kPrefetch], pb[kPrefetch];  // prefetched p rows (cell a / cell b)
+    V da[kPrefetch], db[kPrefetch];  // prefetched d rows
+};
+
+// One relaxation (poisson.cpp:63-112).
+template <class B, bool EDGE, bool DX1>
+SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, typename B::V w,
+                           typename B::V e, typename B::V s, typename B::V n, typename B::V d,
+                           const EdgeCell<B> &ec, RowFacts rf)
+{
+    using V = typename B::V;
+    V sum;
+    V k;
+    if (EDGE) {
+        const V z = rf.full ? ec.z_full : bk.splat(0.0f);
+        k = rf.full ? ec.k_full : ec.k_part;
+        sum = (((z + w) + e) + s) + n;
+    } else {
+        k = bk.splat(-0.25f);
+        sum = ((w + e) + s) + n;
+    }
+    const V rhs = DX1 ? d : c.dx * d;
+    const V gs = k * (rhs - sum);
+    V out = c.one_minus_omega * own + c.omega * gs;
+    if (EDGE) out = bk.select(bk.mask_and(ec.in, rf.in_dom), out, bk.splat(-0.0f));
+    return out;
+}
+
+// The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U)
+// enters, row y - NS leaves.  U = (y - y_start) mod 6 is a compile-time constant.
+template <class B, int NS, bool EDGE, bool DX1, int U>
+SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
+                    const EdgeCell<B> &ecb, int y, int ring_pos, int out_begin, int out_end)
+{
+    using V = typename B::V;
+    constexpr int RING = ring_rows(NS);
+
+    // ---- row y enters: hand it to version 0, park its d in the ring, refill the slot ----
+    {
+        const V a = pp.pa[U], b = pp.pb[U];
+        const V fa = pp.da[U], fb = pp.db[U];
+        bk.load_row(y + kPrefetch, pp.pa[U], pp.pb[U], pp.da[U], pp.db[U]);
+        constexpr bool ev = is_even(U);
+        pp.E[0][wrap3(U)] = ev ? a : b;
+        pp.O[0][wrap3(U)] = ev ? b : a;
+        bk.ring_store(ring_pos, 0, ev ? fa : fb);  // plane 0: d of the E cell
+        bk.ring_store(ring_pos, 1, ev ? fb : fa);  // plane 1: d of the O cell
+    }
+
+#pragma unroll
+    for (int m = 1; m <= NS / 2; ++m) {
+        // ---- E_m of row y - (2m - 1) ----
+        {
+            const int lag = 2 * m - 1;
+            const int r = y - lag;
+            const int rel = U - lag;                 // compile time after unrolling
+            const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
+            const bool ev = is_even(rel);            // E cell is `a` in even rows
+            int rp = ring_pos - lag;
+            if (rp < 0) rp += RING;
+            const V own = pp.E[m - 1][s0];
+            const V oc = pp.O[m - 1][s0];
+            const V w = ev ? bk.from_lower_lane(oc) : oc;
+            const V e = ev ? oc : bk.from_upper_lane(oc);
+            const V d = bk.ring_load(rp, 0);
+            const RowFacts rf = bk.row_facts(r);
+            pp.E[m][s0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[m - 1][sm], pp.O[m - 1][sp],
+                                               d, ev ? eca : ecb, rf);
+        }
+        // ---- O_m of row y - 2m ----
+        {
+            const int lag = 2 * m;
+            const int r = y - lag;
+            const int rel = U - lag;
+            const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
+            const bool ev = is_even(rel);            // O cell is `b` in even rows
+            int rp = ring_pos - lag;
+            if (rp < 0) rp += RING;
+            const V own = pp.O[m - 1][s0];
+            const V oc = pp.E[m][s0];
+            const V w = ev ? oc : bk.from_lower_lane(oc);
+            const V e = ev ? bk.from_upper_lane(oc) : oc;
+            const V d = bk.ring_load(rp, 1);
+            const RowFacts rf = bk.row_facts(r);
+            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[m][sm], pp.E[m][sp], d,
+                                              ev ? ecb : eca, rf);
+            if (m < NS / 2) {
+                pp.O[m][s0] = res;
+            } else if (r >= out_begin && r < out_end) {  // finished row leaves the pipeline
+                if (ev)
+                    bk.store_row(r, oc, res);
+                else
+                    bk.store_row(r, res, oc);
+            }
+        }
+    }
+}
+
+// Stream one tile: output rows [out_begin, out_end), all NS passes.
+template <class B, int NS, bool EDGE, bool DX1>
+SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
+                        const EdgeCell<B> &ecb, int out_begin, int out_end)
+{
+    static_assert(NS >= 2 && NS % 2 == 0, "fuse an even number of colour passes");
+    constexpr int RING = ring_rows(NS);
+    Pipe<B, NS> pp;
+    bk.poison(pp);  // no-op on the GPU; NaN-fills in the emulator to prove nothing stale leaks
+
+    // first input row: NS below the first output row, rounded down to an even row so that
+    // row parity == iteration parity
+    int y = out_begin - NS;
+    y -= (y & 1);
+    const int y_stop = out_end + NS;  // first row that need not enter
+
+#pragma unroll
+    for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
+
+    int ring_pos = 0;
+    while (y < y_stop) {
+#define SFL_SOR_STEP(U)                                                                   \
+    iterate<B, NS, EDGE, DX1, U>(bk, pp, c, eca, ecb, y + U, ring_pos, out_begin, out_end); \
+    ring_pos = (ring_pos + 1 == RING) ? 0 : ring_pos + 1;
+        SFL_SOR_STEP(0)
+        SFL_SOR_STEP(1)
+        SFL_SOR_STEP(2)
+        SFL_SOR_STEP(3)
+        SFL_SOR_STEP(4)
+        SFL_SOR_STEP(5)
+#undef SFL_SOR_STEP
+        y += kUnroll;
+    }
+}
+
+// ---- tiling arithmetic shared by the launcher, the kernel and the emulator -----------------
+struct Tiling {
+    int ns;          // passes fused
+    int dim_x;
+    int g_begin, g_end;   // output rows
+    int rows_per_chunk;
+    int n_strips, n_chunks;
+};
+
+SFL_HD int strip_step(int ns) { return kTileCols - 2 * ns; }  // output columns per strip
+
+SFL_HD Tiling make_tiling(int ns, int dim_x, int g_begin, int g_end, int rows_per_chunk)
+{
+    Tiling t;
+    t.ns = ns;
+    t.dim_x = dim_x;
+    t.g_begin = g_begin;
+    t.g_end = g_end;
+    t.rows_per_chunk = rows_per_chunk;
+    t.n_strips = (dim_x + strip_step(ns) - 1) / strip_step(ns);
+    t.n_chunks = (g_end - g_begin + rows_per_chunk - 1) / rows_per_chunk;
+    return t;
+}
+
+// column of lane 0's cell `a` for a strip (may be negative: columns left of the domain)
+SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t.ns) - t.ns; }
+
+// does the tile (strip, chunk) touch the domain boundary (=> EDGE path)?
+SFL_HD bool tile_touches_boundary(const Tiling &t, int strip, int chunk, int gdim_y)
+{
+    const int x0 = strip_x0(t, strip);
+    const int r0 = t.g_begin + chunk * t.rows_per_chunk;
+    const int r1 = (r0 + t.rows_per_chunk < t.g_end) ? r0 + t.rows_per_chunk : t.g_end;
+    // rows entering the pipeline: [r0 - ns - 1, r1 + ns + kUnroll); columns [x0, x0 + 128)
+    return x0 <= 0 || x0 + kTileCols >= t.dim_x || r0 - t.ns - 1 <= 0 ||
+           r1 + t.ns + kUnroll >= gdim_y;
+}
+
+}  // namespace sor
+}  // namespace sfl

@@ -1,0 +1,378 @@
+// stencil_kernels.hip -- advection, divergence, pressure-gradient, baseline SOR colour pass,
+// zero fill and force injection for gfx950 (MI355X).
+//
+// Numerics contract: this file is compiled with -ffp-contract=off; every
+// product and sum below is individually rounded in the order the reference evaluates it, so
+// results are bit-identical to the reference built without contraction.  Do not "simplify"
+// expressions such as `0.0f + w` (it maps -0 to +0) or reassociate sums.
+//
+// Reference citations are file:line under /root/reference/ESP32-fluid-simulation/.
+#include "kernels.h"
+
+namespace sfl {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ size_t lcell(const Slab &g, int i, int gj)
+{
+    return (size_t)(gj - g.grow0) * (size_t)g.dim_x + (size_t)i;
+}
+
+// lerp(t, a, b) = a*(1-t) + b*t  (advect.h:13-16)
+__device__ __forceinline__ float mix1(float t, float a, float b)
+{
+    const float wa = 1.0f - t;
+    const float pa = a * wa;
+    const float pb = b * t;
+    return pa + pb;
+}
+
+// uq32.h:13 / :15
+__device__ __forceinline__ uint32_t uq_narrow(float x) { return (uint32_t)(x + 0.5f); }
+__device__ __forceinline__ float uq_widen(uint32_t raw) { return (float)raw; }
+
+struct SrcPos {
+    bool x_under, y_under, x_oob, y_oob;
+    int ci, cj;
+    float di, dj;
+};
+
+// advect.h:26-35
+__device__ __forceinline__ SrcPos classify(float si, float sj, int dim_x, int gdim_y)
+{
+    SrcPos s;
+    const bool x_over = si >= (float)(dim_x - 1);
+    const bool y_over = sj >= (float)(gdim_y - 1);
+    const float fi = floorf(si), fj = floorf(sj);
+    s.x_under = si < 0.0f;
+    s.y_under = sj < 0.0f;
+    s.x_oob = s.x_under || x_over;
+    s.y_oob = s.y_under || y_over;
+    s.di = si - fi;
+    s.dj = sj - fj;
+    s.ci = s.x_oob ? (s.x_under ? 0 : dim_x - 1) : (int)fi;
+    s.cj = s.y_oob ? (s.y_under ? 0 : gdim_y - 1) : (int)fj;
+    return s;
+}
+
+// advect.h:62-70
+__device__ __forceinline__ float wall_discount(const SrcPos &s, float si, float sj, int dim_x,
+                                               int gdim_y)
+{
+    float factor = 1.0f;
+    if (s.x_oob) {
+        const float over = s.x_under ? -si : si - (float)(dim_x - 1);
+        factor *= (over < 0.5f) ? (1.0f - 2.0f * over) : 0.0f;
+    }
+    if (s.y_oob) {
+        const float over = s.y_under ? -sj : sj - (float)(gdim_y - 1);
+        factor *= (over < 0.5f) ? (1.0f - 2.0f * over) : 0.0f;
+    }
+    return factor;
+}
+
+// rows of p touched by a sample at s: [cj, cj + (y in range ? 1 : 0)]
+__device__ __forceinline__ bool rows_available(const SrcPos &s, int valid_begin, int valid_end)
+{
+    const int last = s.cj + (s.y_oob ? 0 : 1);
+    return s.cj >= valid_begin && last < valid_end;
+}
+
+// ---- advect<Vector2<float>, float>  (advect.h:24-85) ---------------------------------
+template <bool NO_SLIP>
+__global__ void __launch_bounds__(kBlock)
+advect_vec2f_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *vel, Slab g,
+                    int g_begin, int valid_begin, int valid_end, float dt, int *halo_flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int gj = g_begin + blockIdx.y;
+    if (i >= g.dim_x) return;
+    const size_t c = lcell(g, i, gj);
+    const float2 u = vel[c];
+    const float si = (float)i - u.x * dt;  // advect.h:81
+    const float sj = (float)gj - u.y * dt;
+    const SrcPos s = classify(si, sj, g.dim_x, g.gdim_y);
+    if (!rows_available(s, valid_begin, valid_end)) {
+        if (halo_flag) atomicOr(halo_flag, 1);
+        return;
+    }
+    const size_t t = lcell(g, s.ci, s.cj);
+    float2 r;
+    if (!s.x_oob && !s.y_oob) {
+        const float2 p11 = p[t], p12 = p[t + g.dim_x], p21 = p[t + 1], p22 = p[t + g.dim_x + 1];
+        r.x = mix1(s.di, mix1(s.dj, p11.x, p12.x), mix1(s.dj, p21.x, p22.x));
+        r.y = mix1(s.di, mix1(s.dj, p11.y, p12.y), mix1(s.dj, p21.y, p22.y));
+    } else {
+        if (s.x_oob && s.y_oob) {
+            r = p[t];
+        } else if (s.x_oob) {
+            const float2 a = p[t], b = p[t + g.dim_x];
+            r.x = mix1(s.dj, a.x, b.x);
+            r.y = mix1(s.dj, a.y, b.y);
+        } else {
+            const float2 a = p[t], b = p[t + 1];
+            r.x = mix1(s.di, a.x, b.x);
+            r.y = mix1(s.di, a.y, b.y);
+        }
+        if (NO_SLIP) {
+            const float f = wall_discount(s, si, sj, g.dim_x, g.gdim_y);
+            r.x = r.x * f;
+            r.y = r.y * f;
+        }
+    }
+    next_p[c] = r;
+}
+
+// ---- advect<Vector3<UQ32>, float>  (advect.h:24-85 + uq32.h) ---------------------------
+struct uq3 {
+    uint32_t x, y, z;
+};
+
+__device__ __forceinline__ uq3 load_uq3(const uint32_t *p, size_t cell)
+{
+    const uint32_t *q = p + 3 * cell;
+    return {q[0], q[1], q[2]};
+}
+
+__device__ __forceinline__ uint32_t uq_mix(float t, uint32_t a, uint32_t b)
+{
+    return uq_narrow(mix1(t, uq_widen(a), uq_widen(b)));
+}
+
+template <bool NO_SLIP>
+__global__ void __launch_bounds__(kBlock)
+advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, const float2 *vel, Slab g,
+                       int g_begin, int valid_begin, int valid_end, float dt, int *halo_flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int gj = g_begin + blockIdx.y;
+    if (i >= g.dim_x) return;
+    const size_t c = lcell(g, i, gj);
+    const float2 u = vel[c];
+    const float si = (float)i - u.x * dt;
+    const float sj = (float)gj - u.y * dt;
+    const SrcPos s = classify(si, sj, g.dim_x, g.gdim_y);
+    if (!rows_available(s, valid_begin, valid_end)) {
+        if (halo_flag) atomicOr(halo_flag, 1);
+        return;
+    }
+    const size_t t = lcell(g, s.ci, s.cj);
+    uq3 r;
+    if (!s.x_oob && !s.y_oob) {
+        const uq3 p11 = load_uq3(p, t), p12 = load_uq3(p, t + g.dim_x);
+        const uq3 p21 = load_uq3(p, t + 1), p22 = load_uq3(p, t + g.dim_x + 1);
+        r.x = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.x), uq_widen(p12.x)),
+                             mix1(s.dj, uq_widen(p21.x), uq_widen(p22.x))));
+        r.y = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.y), uq_widen(p12.y)),
+                             mix1(s.dj, uq_widen(p21.y), uq_widen(p22.y))));
+        r.z = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.z), uq_widen(p12.z)),
+                             mix1(s.dj, uq_widen(p21.z), uq_widen(p22.z))));
+    } else {
+        // "T p_edge" narrows once (advect.h:45-54); returned raw when !no_slip (:57-59)
+        if (s.x_oob && s.y_oob) {
+            r = load_uq3(p, t);
+        } else if (s.x_oob) {
+            const uq3 a = load_uq3(p, t), b = load_uq3(p, t + g.dim_x);
+            r = {uq_mix(s.dj, a.x, b.x), uq_mix(s.dj, a.y, b.y), uq_mix(s.dj, a.z, b.z)};
+        } else {
+            const uq3 a = load_uq3(p, t), b = load_uq3(p, t + 1);
+            r = {uq_mix(s.di, a.x, b.x), uq_mix(s.di, a.y, b.y), uq_mix(s.di, a.z, b.z)};
+        }
+        if (NO_SLIP) {  // widen, scale, narrow again (advect.h:71)
+            const float f = wall_discount(s, si, sj, g.dim_x, g.gdim_y);
+            r.x = uq_narrow(uq_widen(r.x) * f);
+            r.y = uq_narrow(uq_widen(r.y) * f);
+            r.z = uq_narrow(uq_widen(r.z) * f);
+        }
+    }
+    uint32_t *o = next_p + 3 * c;
+    o[0] = r.x;
+    o[1] = r.y;
+    o[2] = r.z;
+}
+
+// ---- calculate_divergence (finitediff.cpp:9-39) -------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+divergence_kernel(float *__restrict__ div, const float2 *__restrict__ v, Slab g, int g_begin,
+                  float two_dx_inv)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int gj = g_begin + blockIdx.y;
+    if (i >= g.dim_x) return;
+    const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+    const size_t c = lcell(g, i, gj);
+    float s;
+    if (i > 0 && i < i_max && gj > 0 && gj < j_max) {  // div_expr_fast, :29
+        const float hx = -v[c - 1].x + v[c + 1].x;
+        const float hy = -v[c - g.dim_x].y + v[c + g.dim_x].y;
+        s = hx + hy;
+    } else {  // div_expr_safe, :15-20: ghost velocity = -own
+        const float2 own = v[c];
+        s = 0.0f;
+        s += (i > 0) ? -v[c - 1].x : own.x;
+        s += (i < i_max) ? v[c + 1].x : -own.x;
+        s += (gj > 0) ? -v[c - g.dim_x].y : own.y;
+        s += (gj < j_max) ? v[c + g.dim_x].y : -own.y;
+    }
+    div[c] = s * two_dx_inv;
+}
+
+// ---- subtract_gradient (finitediff.cpp:41-82), in place on v ------------------------------
+__global__ void __launch_bounds__(kBlock)
+subtract_gradient_kernel(float2 *v, const float *__restrict__ p, Slab g, int g_begin,
+                         float two_dx_inv)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int gj = g_begin + blockIdx.y;
+    if (i >= g.dim_x) return;
+    const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+    const size_t c = lcell(g, i, gj);
+    const float pc = p[c];
+    const float pw = (i > 0) ? p[c - 1] : pc;
+    const float pe = (i < i_max) ? p[c + 1] : pc;
+    const float ps = (gj > 0) ? p[c - g.dim_x] : pc;
+    const float pn = (gj < j_max) ? p[c + g.dim_x] : pc;
+    const float gx = (pe - pw) * two_dx_inv;
+    const float gy = (pn - ps) * two_dx_inv;
+    float2 u = v[c];
+    u.x = u.x - gx;
+    u.y = u.y - gy;
+    v[c] = u;
+}
+
+// ---- baseline SOR colour pass (poisson.cpp:14-112), in place --------------------------------
+__global__ void __launch_bounds__(kBlock)
+sor_half_sweep_kernel(float *p, const float *__restrict__ d, Slab g, int g_begin, int colour,
+                      SorParams prm)
+{
+    const int gj = g_begin + blockIdx.y;
+    const int i = 2 * (blockIdx.x * kBlock + threadIdx.x) + ((gj + colour) & 1);
+    if (i >= g.dim_x) return;
+    const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+    const size_t c = lcell(g, i, gj);
+    float p_gs;
+    if (i > 0 && i < i_max && gj > 0 && gj < j_max) {  // pois_sor_fast, :107-109
+        const float sum = p[c - 1] + p[c + 1] + p[c - g.dim_x] + p[c + g.dim_x];
+        p_gs = -0.25f * (prm.dx * d[c] - sum);
+    } else {  // pois_gs_safe, :67-89
+        float sum = 0.0f;
+        int n = 0;
+        if (i > 0) { sum += p[c - 1]; ++n; }
+        if (i < i_max) { sum += p[c + 1]; ++n; }
+        if (gj > 0) { sum += p[c - g.dim_x]; ++n; }
+        if (gj < j_max) { sum += p[c + g.dim_x]; ++n; }
+        const float k = (n == 2) ? (float)(-1.0 / 2.0) : (n == 3) ? (float)(-1.0 / 3.0) : -0.25f;
+        p_gs = k * (prm.dx * d[c] - sum);
+    }
+    p[c] = prm.one_minus_omega * p[c] + prm.omega * p_gs;  // :98, :111
+}
+
+__global__ void __launch_bounds__(kBlock)
+zero_rows_kernel(float *f, size_t first, size_t count)
+{
+    size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (; k < count; k += stride) f[first + k] = 0.0f;
+}
+
+// Sequential on purpose: later entries overwrite earlier ones like the sketch's queue drain
+// (ino:264-269); n is a handful of touch events.
+__global__ void apply_forces_kernel(float2 *v, Slab g, int g_begin, int g_end,
+                                    const int *cells_ij, const float *vel_xy, int n)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int k = 0; k < n; ++k) {
+        const int i = cells_ij[2 * k], gj = cells_ij[2 * k + 1];
+        if (i < 0 || i >= g.dim_x || gj < g_begin || gj >= g_end) continue;
+        v[lcell(g, i, gj)] = make_float2(vel_xy[2 * k], vel_xy[2 * k + 1]);
+    }
+}
+
+inline dim3 grid_cells(int cells_per_row, int rows) { return dim3((cells_per_row + kBlock - 1) / kBlock, rows, 1); }
+
+}  // namespace
+
+hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
+                               Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
+                               float dt, bool no_slip, int *halo_flag)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const dim3 grid = grid_cells(g.dim_x, g_end - g_begin);
+    auto *o = reinterpret_cast<float2 *>(next_p);
+    auto *pi = reinterpret_cast<const float2 *>(p);
+    auto *vi = reinterpret_cast<const float2 *>(vel);
+    if (no_slip)
+        advect_vec2f_kernel<true><<<grid, kBlock, 0, s>>>(o, pi, vi, g, g_begin, valid_begin,
+                                                          valid_end, dt, halo_flag);
+    else
+        advect_vec2f_kernel<false><<<grid, kBlock, 0, s>>>(o, pi, vi, g, g_begin, valid_begin,
+                                                           valid_end, dt, halo_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
+                                  const float *vel, Slab g, int g_begin, int g_end,
+                                  int valid_begin, int valid_end, float dt, bool no_slip,
+                                  int *halo_flag)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const dim3 grid = grid_cells(g.dim_x, g_end - g_begin);
+    auto *vi = reinterpret_cast<const float2 *>(vel);
+    if (no_slip)
+        advect_vec3uq32_kernel<true><<<grid, kBlock, 0, s>>>(next_p, p, vi, g, g_begin,
+                                                             valid_begin, valid_end, dt, halo_flag);
+    else
+        advect_vec3uq32_kernel<false><<<grid, kBlock, 0, s>>>(next_p, p, vi, g, g_begin,
+                                                              valid_begin, valid_end, dt, halo_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
+                             int g_end, float two_dx_inv)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    divergence_kernel<<<grid_cells(g.dim_x, g_end - g_begin), kBlock, 0, s>>>(
+        div, reinterpret_cast<const float2 *>(v), g, g_begin, two_dx_inv);
+    return hipGetLastError();
+}
+
+hipError_t launch_subtract_gradient(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
+                                    int g_end, float two_dx_inv)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    subtract_gradient_kernel<<<grid_cells(g.dim_x, g_end - g_begin), kBlock, 0, s>>>(
+        reinterpret_cast<float2 *>(v), p, g, g_begin, two_dx_inv);
+    return hipGetLastError();
+}
+
+hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g, int g_begin,
+                                 int g_end, int colour, SorParams prm)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    sor_half_sweep_kernel<<<grid_cells((g.dim_x + 1) / 2, g_end - g_begin), kBlock, 0, s>>>(
+        p, d, g, g_begin, colour, prm);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_end)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const size_t first = (size_t)(g_begin - g.grow0) * g.dim_x;
+    const size_t count = (size_t)(g_end - g_begin) * g.dim_x;
+    const size_t want = (count + kBlock - 1) / kBlock;
+    const int blocks = (int)(want < 4096 ? want : 4096);
+    zero_rows_kernel<<<blocks, kBlock, 0, s>>>(f, first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
+                               const int *cells_ij, const float *vel_xy, int n)
+{
+    if (n <= 0 || g_end <= g_begin) return hipSuccess;
+    apply_forces_kernel<<<1, 64, 0, s>>>(reinterpret_cast<float2 *>(v), g, g_begin, g_end,
+                                         cells_ij, vel_xy, n);
+    return hipGetLastError();
+}
+
+}  // namespace sfl

@@ -1,0 +1,214 @@
+/*
+ * sfl.h -- C ABI of the MI355X-native stable-fluids hot path ("sfl").
+ *
+ * This is the drop-in boundary for the sim-task arithmetic of
+ * colonelwatch/ESP32-fluid-simulation.  Every entry point is `extern "C"`, takes
+ * plain pointers / sizes / scalars and returns an int status (0 = SFL_OK, <0 = error,
+ * text via sfl_last_error()).  The reference's own functions return void and check
+ * nothing; the C++ drop-in headers in include/sfl/ keep those
+ * exact signatures on top of this ABI.
+ *
+ * Citations are file:line under /root/reference/ESP32-fluid-simulation/.
+ *
+ * Data layout (identical to the reference, operations.h:7-9): element (i, j) of a
+ * dim_x * dim_y field at index dim_x*j + i, i fastest.  Velocity = interleaved
+ * {x, y} float32 (Vector2<float>, vector.h:4-57, 8 B); dye = interleaved {x, y, z}
+ * uint32 raw values (Vector3<UQ32>, vector.h:63-122 + uq32.h:8-16, 12 B);
+ * pressure / divergence = float32.
+ *
+ * Three groups of entry points:
+ *   1. host-pointer drop-ins  sfl_host_*      the reference signatures + status; upload,
+ *                                             run the HIP kernels, download (parity / porting aid)
+ *   2. solver contexts        sfl_create ...  device-resident fields for one GPU's row slab of
+ *                                             the domain, operators, RCCL halo exchange
+ *   3. utilities              version, errors, device query, slab partition arithmetic
+ *
+ * There is NO CPU fallback anywhere behind this header: without a usable GPU every
+ * compute entry point fails with SFL_ERR_HIP.
+ */
+#ifndef SFL_H
+#define SFL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFL_API __attribute__((visibility("default")))
+
+#define SFL_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------- */
+#define SFL_OK 0
+#define SFL_ERR_INVALID (-1) /* bad argument: NULL, dim < 2, iters < 0, aliasing rule broken   */
+#define SFL_ERR_HIP (-2)     /* HIP runtime / no device / kernel launch failure               */
+#define SFL_ERR_RCCL (-3)    /* RCCL failure                                                  */
+#define SFL_ERR_NOMEM (-4)   /* device or host allocation failed                              */
+#define SFL_ERR_STATE (-5)   /* call not valid in this context state (e.g. comm not attached) */
+#define SFL_ERR_HALO (-6)    /* a back-trace left the slab's advect halo (multi-GPU only)     */
+
+/* ---- field identifiers of a context ----------------------------------------------- */
+#define SFL_FIELD_VELOCITY 0   /* Vector2<float>  velocity_field (ino:54)                    */
+#define SFL_FIELD_COLOR 1      /* Vector3<UQ32>   color_field    (ino:55)                    */
+#define SFL_FIELD_DIVERGENCE 2 /* float           div_v          (ino:272)                   */
+#define SFL_FIELD_PRESSURE 3   /* float           p              (ino:273)                   */
+
+/* ---- tunables (sfl_set_option) ------------------------------------------------------ */
+#define SFL_OPT_SOR_KERNEL 0   /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
+                                  2 = fused multi-half-sweep streaming kernel                   */
+#define SFL_OPT_SOR_FUSE 1     /* half-sweeps fused per launch by kernel 2 (even, 2..16)        */
+#define SFL_OPT_ADVECT_HALO 2  /* rows of advected-field halo kept per side on a slab (>= 1)    */
+#define SFL_OPT_SOR_ROWS 3     /* output rows per wave chunk of kernel 2 (0 = auto)             */
+#define SFL_OPT_TRANSPORT 4    /* 0 = RCCL send/recv, 1 = in-process copies between the virtual
+                                  ranks of a sfl_group (single device; test / bring-up)         */
+
+typedef struct sfl_context sfl_context;
+
+/* =====================================================================================
+ * 3. utilities
+ * ===================================================================================== */
+SFL_API int sfl_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+SFL_API const char *sfl_last_error(void);
+/* Number of visible HIP devices (0 and SFL_ERR_HIP when there is none). */
+SFL_API int sfl_device_count(int *count);
+/* Name / CU count / memory of a device; any out pointer may be NULL. */
+SFL_API int sfl_device_info(int device, char *name, size_t name_cap, int *compute_units,
+                            size_t *total_mem_bytes);
+
+/* Row-slab partition of dim_y rows over nranks: rank g owns global rows
+ * [dim_y*g/nranks, dim_y*(g+1)/nranks).  Pure arithmetic, no GPU needed.                */
+SFL_API int sfl_slab_rows(int dim_y, int nranks, int rank, int *row_begin, int *row_end);
+
+/* One step of a rank's program (sfl_plan_poisson): either a halo exchange with both
+ * neighbouring slabs or a compute launch.  Row ranges are GLOBAL rows.                        */
+typedef struct sfl_plan_step {
+    int32_t kind;         /* SFL_STEP_*                                                       */
+    int32_t field;        /* EXCHANGE: SFL_FIELD_* whose halo rows are refreshed              */
+    int32_t rows;         /* EXCHANGE: rows per side (sent from / received next to the owned
+                             block); 0 on compute steps                                       */
+    int32_t g_begin;      /* compute: first output row                                        */
+    int32_t g_end;        /* compute: one past the last output row                            */
+    int32_t nsweeps;      /* SOR: colour passes executed by this launch.  Pass j (1-based)
+                             covers rows [g_begin-(nsweeps-j), g_end+(nsweeps-j)) clipped to
+                             the domain, i.e. halo rows are recomputed redundantly so that
+                             the output rows are exact                                        */
+    int32_t first_colour; /* SOR: colour of pass 1 (0 = even (i+j), poisson.cpp:22)           */
+    int32_t from_zero;    /* SOR: p is implicitly zero on entry (poisson.cpp:117-119)         */
+} sfl_plan_step;
+
+#define SFL_STEP_EXCHANGE 1 /* refresh `rows` ghost rows per side of `field`                   */
+#define SFL_STEP_SOR 2      /* nsweeps colour passes -> output rows [g_begin, g_end)           */
+#define SFL_STEP_ZERO 3     /* zero-fill p on every local row (baseline kernel only)           */
+
+/* Program of one poisson_solve on slab `rank` of `nranks`: kernel = 1 (one colour pass per
+ * launch, 1-row exchange before every pass but the first) or 2 (fused: `fuse` passes per
+ * launch, `fuse`-row exchange before every launch but the first, plus one exchange of the
+ * right-hand side up front).  Writes at most `cap` steps, returns the total in *n_steps.
+ * Pure arithmetic, no GPU needed; the GPU executor walks exactly this program.                */
+SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
+                             sfl_plan_step *steps, int cap, int *n_steps);
+
+/* Pass plan of one poisson_solve: 2*iters half-sweeps are executed as `*n_passes` launches of
+ * at most `fuse` half-sweeps each (the last one may be shorter); passes[k] receives the
+ * number of half-sweeps of launch k when passes != NULL (capacity cap).  On a slab, every
+ * pass after the first is preceded by one halo exchange of passes[k] rows of p per side;
+ * the first needs none because p starts at zero everywhere (poisson.cpp:117-119).
+ * Pure arithmetic, no GPU needed.                                                           */
+SFL_API int sfl_sor_pass_plan(int iters, int fuse, int *n_passes, int *passes, int cap);
+
+/* =====================================================================================
+ * 1. host-pointer drop-ins: the reference's operator signatures + int status.
+ *    Pointers are HOST memory; each call uploads, runs the HIP kernels on `device 0`
+ *    (or SFL_DEVICE from the environment) and downloads.  Intended for parity tests and as
+ *    the first step of a port; production callers keep fields on the device (group 2).
+ * ===================================================================================== */
+
+/* advect<Vector2<float>, float>   advect.h:74-85 (sample :24-72).  next_p must not alias p;
+ * p may alias vel (self-advection, ino:253).                                               */
+SFL_API int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int dim_x,
+                                  int dim_y, float dt, int no_slip);
+/* advect<Vector3<UQ32>, float>    advect.h:74-85 with uq32.h:13,15 (ino:282)               */
+SFL_API int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *vel,
+                                     int dim_x, int dim_y, float dt, int no_slip);
+/* calculate_divergence            finitediff.h:6-7, finitediff.cpp:9-39                     */
+SFL_API int sfl_host_calculate_divergence(float *div, const float *v, int dim_x, int dim_y,
+                                          float dx);
+/* subtract_gradient (in place)    finitediff.h:9-10, finitediff.cpp:41-82                   */
+SFL_API int sfl_host_subtract_gradient(float *v, const float *p, int dim_x, int dim_y, float dx);
+/* poisson_solve                   poisson.h:4-5, poisson.cpp:114-125                        */
+SFL_API int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, float dx,
+                                   int iters, float omega);
+
+/* =====================================================================================
+ * 2. solver contexts: one context = one GPU's row slab, fields resident in HBM.
+ * ===================================================================================== */
+
+/* Whole domain on one device (rank 0 of 1). */
+SFL_API int sfl_create(sfl_context **out, int device, int dim_x, int dim_y);
+/* Row slab `rank` of `nranks` (sfl_slab_rows) of a dim_x * dim_y domain on `device`.
+ * Neighbouring slabs exchange halos through RCCL once sfl_comm_attach() has run, or through
+ * in-process copies when the contexts were joined with sfl_group_link().                    */
+SFL_API int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int rank,
+                            int nranks);
+SFL_API int sfl_destroy(sfl_context *ctx);
+
+SFL_API int sfl_set_option(sfl_context *ctx, int option, int value);
+SFL_API int sfl_get_option(sfl_context *ctx, int option, int *value);
+
+/* Geometry of this context's slab: global rows [row_begin, row_end). */
+SFL_API int sfl_slab_of(sfl_context *ctx, int *row_begin, int *row_end, int *rank, int *nranks);
+
+/* --- RCCL bootstrap: rank 0 creates the id, the launcher distributes the bytes (e.g.
+ *     torch.distributed broadcast), every rank attaches.  id_bytes = 128.                  */
+SFL_API int sfl_comm_unique_id(void *id_out, size_t id_bytes);
+SFL_API int sfl_comm_attach(sfl_context *ctx, const void *id, size_t id_bytes);
+/* In-process transport between virtual ranks living on ONE device (bring-up / tests):
+ * ctxs[r] must be slab r of nranks == n, all created on the same device.                   */
+SFL_API int sfl_group_link(sfl_context **ctxs, int n);
+
+/* --- field I/O: the OWNED rows of this slab, host <-> device, synchronous.
+ *     `host` holds (row_end-row_begin) * dim_x elements of the field's element type.       */
+SFL_API int sfl_upload(sfl_context *ctx, int field, const void *host, size_t bytes);
+SFL_API int sfl_download(sfl_context *ctx, int field, void *host, size_t bytes);
+/* Device pointer of the first OWNED row (for zero-copy interop, e.g. torch tensors made
+ * with from_blob; the context keeps ownership).                                           */
+SFL_API int sfl_field_device_ptr(sfl_context *ctx, int field, void **dev_ptr);
+
+/* --- operators on the resident fields, asynchronous on the context's stream.
+ *     On a slab each call performs the halo exchanges it needs.  All ranks of a group must
+ *     issue the same calls in the same order (they contain matched send/recv pairs).        */
+/* velocity <- advect(velocity, velocity, dt, no_slip)       ino:252-256 */
+SFL_API int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip);
+/* colour   <- advect(colour, velocity, dt, no_slip)         ino:281-287 */
+SFL_API int sfl_advect_color(sfl_context *ctx, float dt, int no_slip);
+/* divergence <- calculate_divergence(velocity, dx)          ino:274     */
+SFL_API int sfl_calculate_divergence(sfl_context *ctx, float dx);
+/* pressure <- poisson_solve(divergence, dx, iters, omega)   ino:275     */
+SFL_API int sfl_poisson_solve(sfl_context *ctx, float dx, int iters, float omega);
+/* velocity <- subtract_gradient(velocity, pressure, dx)     ino:276     */
+SFL_API int sfl_subtract_gradient(sfl_context *ctx, float dx);
+/* One sim step in the order of ino:252-287: advect velocity (no-slip), [apply queued
+ * forces], divergence, poisson_solve, subtract_gradient, advect colour (free-slip).         */
+SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega);
+/* Queue point forces applied by the next sfl_step between the velocity advection and the
+ * divergence (ino:264-269): velocity[index(cells[2k], cells[2k+1])] = (vel[2k], vel[2k+1])
+ * in SIMULATION coordinates (the sketch's x/y swap is the caller's business).               */
+SFL_API int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n);
+
+/* --- synchronisation / timing on the context's stream ---------------------------------- */
+SFL_API int sfl_synchronize(sfl_context *ctx);
+/* HIP-event stopwatch on the compute stream: start, run work, stop -> elapsed ms (blocks
+ * until the stop event has completed).                                                     */
+SFL_API int sfl_timer_start(sfl_context *ctx);
+SFL_API int sfl_timer_stop(sfl_context *ctx, float *elapsed_ms);
+/* Launch statistics of the last sfl_poisson_solve on this context: kernel launches, halo
+ * exchanges, half-sweeps fused per launch.  Any out pointer may be NULL.                    */
+SFL_API int sfl_last_solve_info(sfl_context *ctx, int *launches, int *exchanges, int *fuse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFL_H */

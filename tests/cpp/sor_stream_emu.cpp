@@ -1,0 +1,232 @@
+// sor_stream_emu.cpp -- CPU emulation of one gfx950 wavefront running the fused SOR pipeline.
+//
+// TEST HARNESS ONLY.  It instantiates the PRODUCT's pipeline (csrc/sor_stream_core.h -- the
+// exact header the GPU kernel is built from) with a backend whose value type is "64 lanes of
+// float", executes tiles one after the other on the CPU and lets pytest compare the result
+// with the oracle bit for bit.  Nothing here is reachable from the product library.
+//
+// What this proves without a GPU: slot rotation, row parity, colour order, the E/O dependency
+// schedule, the -0.0f boundary algebra, tile validity margins and the tiling arithmetic.
+// What it cannot prove: the DPP lane shifts, LDS addressing and load/store guards of the real
+// backend (sor_fused.hip) -- those are covered by the `-m gpu` parity tests.
+//
+// Build: g++ -std=c++17 -O1 -ffp-contract=off -shared -fPIC   (tests/cpp/Makefile)
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "sor_stream_core.h"
+
+namespace {
+
+struct V64 {
+    float l[64];
+};
+struct M64 {
+    bool l[64];
+};
+
+#define EMU_BINOP(OP)                                      \
+    inline V64 operator OP(const V64 &a, const V64 &b)     \
+    {                                                      \
+        V64 r;                                             \
+        for (int i = 0; i < 64; ++i) r.l[i] = a.l[i] OP b.l[i]; \
+        return r;                                          \
+    }
+EMU_BINOP(+)
+EMU_BINOP(-)
+EMU_BINOP(*)
+#undef EMU_BINOP
+
+struct EmuBackend {
+    using V = V64;
+    using M = M64;
+
+    const float *p_in;
+    const float *d;
+    float *p_out;
+    int dim_x, gdim_y, grow0, row_lo, row_hi;
+    int x0;       // column of lane 0's cell a
+    int out_lo, out_hi;
+    bool vec2;    // emulate the 8-byte access variant (pair handled as a whole)
+    bool poison_on;
+    std::vector<float> ring;  // [slot][plane][lane]
+
+    V splat(float x) const
+    {
+        V r;
+        for (int i = 0; i < 64; ++i) r.l[i] = x;
+        return r;
+    }
+    V select(const M &m, const V &a, const V &b) const
+    {
+        V r;
+        for (int i = 0; i < 64; ++i) r.l[i] = m.l[i] ? a.l[i] : b.l[i];
+        return r;
+    }
+    M mask_and(const M &m, bool row) const
+    {
+        M r;
+        for (int i = 0; i < 64; ++i) r.l[i] = m.l[i] && row;
+        return r;
+    }
+    // DPP wave_shr:1 / wave_shl:1 with bound_ctrl: the missing lane reads 0
+    V from_lower_lane(const V &x) const
+    {
+        V r;
+        r.l[0] = 0.0f;
+        for (int i = 1; i < 64; ++i) r.l[i] = x.l[i - 1];
+        return r;
+    }
+    V from_upper_lane(const V &x) const
+    {
+        V r;
+        r.l[63] = 0.0f;
+        for (int i = 0; i < 63; ++i) r.l[i] = x.l[i + 1];
+        return r;
+    }
+    sfl::sor::RowFacts row_facts(int r) const
+    {
+        return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
+    }
+    template <class P>
+    void poison(P &pp) const
+    {
+        if (!poison_on) return;
+        // every pipeline register starts as NaN: a stale read would surface in the output
+        float *f = reinterpret_cast<float *>(&pp);
+        for (size_t k = 0; k < sizeof(P) / sizeof(float); ++k)
+            f[k] = std::numeric_limits<float>::quiet_NaN();
+    }
+    void load_row(int r, V &pa, V &pb, V &da, V &db) const
+    {
+        const bool row_ok = r >= row_lo && r < row_hi;
+        const bool in_dom = r >= 0 && r < gdim_y;
+        for (int i = 0; i < 64; ++i) {
+            const int xa = x0 + 2 * i;
+            const bool a_in = xa >= 0 && xa < dim_x, b_in = xa + 1 >= 0 && xa + 1 < dim_x;
+            const float pdef = (in_dom && p_in == nullptr) ? 0.0f : -0.0f;
+            float va = a_in ? pdef : -0.0f, vb = b_in ? pdef : -0.0f, fa = 0.0f, fb = 0.0f;
+            if (row_ok) {
+                const size_t c = (size_t)(r - grow0) * dim_x + xa;
+                if (vec2 ? a_in : a_in) {
+                    fa = d[c];
+                    if (p_in) va = p_in[c];
+                }
+                if (vec2 ? a_in : b_in) {
+                    fb = d[c + 1];
+                    if (p_in) vb = p_in[c + 1];
+                }
+            }
+            pa.l[i] = va;
+            pb.l[i] = vb;
+            da.l[i] = fa;
+            db.l[i] = fb;
+        }
+    }
+    void store_row(int r, const V &a, const V &b) const
+    {
+        for (int i = 0; i < 64; ++i) {
+            const int xa = x0 + 2 * i;
+            const bool a_in = xa >= 0 && xa < dim_x, b_in = xa + 1 >= 0 && xa + 1 < dim_x;
+            const bool a_out = a_in && xa >= out_lo && xa < out_hi;
+            const bool b_out = b_in && xa + 1 >= out_lo && xa + 1 < out_hi;
+            const size_t c = (size_t)(r - grow0) * dim_x + xa;
+            if (vec2 ? a_out : a_out) p_out[c] = a.l[i];
+            if (vec2 ? a_out : b_out) p_out[c + 1] = b.l[i];
+        }
+    }
+    void ring_store(int slot, int plane, const V &x)
+    {
+        std::memcpy(&ring[(size_t)(slot * 2 + plane) * 64], x.l, sizeof(x.l));
+    }
+    V ring_load(int slot, int plane) const
+    {
+        V r;
+        std::memcpy(r.l, &ring[(size_t)(slot * 2 + plane) * 64], sizeof(r.l));
+        return r;
+    }
+};
+
+sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
+{
+    sfl::sor::EdgeCell<EmuBackend> ec;
+    const float k2 = (float)(-1.0 / 2.0), k3 = (float)(-1.0 / 3.0), k4 = -0.25f;
+    for (int i = 0; i < 64; ++i) {
+        const int x = x0 + 2 * i + which;
+        const int nh = (x > 0 ? 1 : 0) + (x < dim_x - 1 ? 1 : 0);
+        ec.in.l[i] = x >= 0 && x < dim_x;
+        ec.k_full.l[i] = (nh == 2) ? k4 : (nh == 1) ? k3 : k2;
+        ec.k_part.l[i] = (nh == 2) ? k3 : k2;
+        ec.z_full.l[i] = (nh == 2) ? -0.0f : 0.0f;
+    }
+    return ec;
+}
+
+template <int NS>
+void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
+               int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
+               bool vec2, bool poison, bool force_edge)
+{
+    using namespace sfl::sor;
+    const Tiling t = make_tiling(NS, dim_x, g_begin, g_end, rows_per_chunk);
+    for (int chunk = 0; chunk < t.n_chunks; ++chunk) {
+        for (int strip = 0; strip < t.n_strips; ++strip) {
+            EmuBackend bk;
+            bk.p_in = p_in;
+            bk.d = d;
+            bk.p_out = p_out;
+            bk.dim_x = dim_x;
+            bk.gdim_y = gdim_y;
+            bk.grow0 = grow0;
+            bk.row_lo = grow0 > 0 ? grow0 : 0;
+            bk.row_hi = (grow0 + lrows < gdim_y) ? grow0 + lrows : gdim_y;
+            bk.x0 = strip_x0(t, strip);
+            bk.out_lo = bk.x0 + NS;
+            bk.out_hi = bk.x0 + kTileCols - NS;
+            bk.vec2 = vec2;
+            bk.poison_on = poison;
+            bk.ring.assign((size_t)ring_rows(NS) * 2 * 64,
+                           poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
+            const int r0 = g_begin + chunk * rows_per_chunk;
+            const int r1 = (r0 + rows_per_chunk < g_end) ? r0 + rows_per_chunk : g_end;
+            Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
+            const bool edge = force_edge || tile_touches_boundary(t, strip, chunk, gdim_y);
+            const bool dx1 = dx == 1.0f;
+            const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
+            if (edge) {
+                if (dx1) stream_tile<EmuBackend, NS, true, true>(bk, c, eca, ecb, r0, r1);
+                else stream_tile<EmuBackend, NS, true, false>(bk, c, eca, ecb, r0, r1);
+            } else {
+                if (dx1) stream_tile<EmuBackend, NS, false, true>(bk, c, eca, ecb, r0, r1);
+                else stream_tile<EmuBackend, NS, false, false>(bk, c, eca, ecb, r0, r1);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
+//        bit2 = force the EDGE path for every tile
+extern "C" __attribute__((visibility("default"))) int
+emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
+              int lrows, int g_begin, int g_end, int ns, float dx, float omega,
+              int rows_per_chunk, int flags)
+{
+    const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4;
+    if (vec2 && (dim_x & 1)) return -1;
+#define EMU_CASE(N)                                                                          \
+    case N:                                                                                  \
+        run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
+                     rows_per_chunk, vec2, poison, force_edge);                              \
+        return 0;
+    switch (ns) {
+        EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
+        EMU_CASE(16)
+    }
+#undef EMU_CASE
+    return -2;
+}

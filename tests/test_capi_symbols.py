@@ -1,0 +1,72 @@
+"""CPU suite: the C-ABI library loads without a GPU, exports every symbol include/sfl.h
+declares, and its GPU-free entry points (version, slab arithmetic, plans, error reporting)
+behave.  No compute call is made here."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sfl.h")).read()
+    return sorted(set(re.findall(r"SFL_API\s+[\w\s\*]+?\b(sfl_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(sfl):
+    lib = sfl.capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sfl.h but not exported"
+    assert sorted(sfl.capi.SIGNATURES) == declared, "ctypes table out of sync with include/sfl.h"
+
+
+def test_version_and_error_reporting_without_gpu(sfl):
+    lib = sfl.capi.lib()
+    assert lib.sfl_abi_version() == 1
+    if sfl.device_count() == 0:
+        with pytest.raises(sfl.SflError) as e:
+            sfl.Solver(16, 16)
+        assert e.value.code == sfl.capi.ERR_HIP  # fails loudly: no CPU fallback
+
+
+def test_slab_rows_partition():
+    import importlib
+    sfl = importlib.import_module("esp32-fluid-simulation_amd")
+    for dim_y, n in [(8192, 8), (81, 2), (81, 3), (100, 7), (16384, 8)]:
+        cuts = [sfl.slab_rows(dim_y, n, r) for r in range(n)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == dim_y
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(n - 1))
+        assert max(e - b for b, e in cuts) - min(e - b for b, e in cuts) <= 1
+    assert sfl.slab_rows(8192, 8, 3) == (3072, 4096)
+
+
+def test_pass_plan(sfl):
+    assert sfl.sor_pass_plan(80, 8) == [8] * 20
+    assert sfl.sor_pass_plan(10, 8) == [8, 8, 4]
+    assert sfl.sor_pass_plan(1, 16) == [2]
+    assert sfl.sor_pass_plan(0, 8) == []
+    with pytest.raises(sfl.SflError):
+        sfl.sor_pass_plan(4, 3)
+
+
+def test_poisson_program_shape(sfl):
+    E, S, Z = sfl.capi.STEP_EXCHANGE, sfl.capi.STEP_SOR, sfl.capi.STEP_ZERO
+    # single rank: no exchanges at all
+    prog = sfl.plan_poisson(8192, 1, 0, 80, 8, 2)
+    assert [s.kind for s in prog] == [S] * 20 and prog[0].from_zero == 1 and prog[1].from_zero == 0
+    # 8 ranks, fused: one rhs exchange + one p exchange before every launch but the first
+    progs = [sfl.plan_poisson(8192, 8, r, 80, 8, 2) for r in range(8)]
+    kinds = [s.kind for s in progs[0]]
+    assert kinds == [E, S] + [E, S] * 19
+    assert progs[0][0].field == sfl.capi.FIELD_DIVERGENCE and progs[0][0].rows == 7
+    assert all(s.rows == 8 and s.field == sfl.capi.FIELD_PRESSURE for s in progs[0][2::2])
+    for r in range(8):  # same skeleton on every rank, own rows as output
+        assert [s.kind for s in progs[r]] == kinds
+        assert all((s.g_begin, s.g_end) == sfl.slab_rows(8192, 8, r) for s in progs[r] if s.kind == S)
+    # baseline: zero fill, then exchange before every colour pass but the first
+    prog = sfl.plan_poisson(100, 2, 1, 2, 8, 1)
+    assert [s.kind for s in prog] == [Z, S, E, S, E, S, E, S]
+    assert [s.first_colour for s in prog if s.kind == S] == [0, 1, 0, 1]
