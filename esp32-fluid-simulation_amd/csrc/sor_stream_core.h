@@ -21,9 +21,11 @@
 // iteration that receives input row y it computes E_m[y-(2m-1)] and O_m[y-2m] for every m, so
 // the finished row y-NS leaves the pipeline NS iterations after it entered.  Every value is
 // used for at most three iterations, hence three register slots per (colour, version),
-// addressed by (row mod 3); the loop is unrolled by 6 (= lcm of slot period 3 and row parity
-// 2) so that every slot and parity is a compile-time constant.  The right-hand side d of a row
-// is needed NS iterations long; it waits in a per-lane ring in LDS (nobody else reads it).
+// addressed by (row mod 3).  The right-hand side d of a row is needed NS iterations long; it
+// waits in a per-lane ring of RING >= NS + 1 rows in LDS (nobody else reads it).  The loop body
+// is unrolled RING times, RING a multiple of 6 (= lcm of slot period 3 and row parity 2), so
+// that every register slot, row parity and ring slot is a compile-time constant: no address
+// arithmetic, no register moves.
 //
 // Validity: a tile is loaded with NS extra columns / rows on every side; pass s of the NS
 // spoils one more ring of cells, the tile's interior [NS from each loaded edge] is exact.
@@ -33,6 +35,7 @@
 //   perimeter sum = ((((+0 + W') + E') + S') + N'        poisson.cpp:69-86 (pois_gs_safe)
 // and both are evaluated as (((z + W) + E) + S) + N with z = -0.0f / +0.0f.
 #pragma once
+#include <utility>
 
 #if defined(__HIPCC__)
 #define SFL_HD __host__ __device__ __forceinline__
@@ -43,13 +46,14 @@
 namespace sfl {
 namespace sor {
 
-constexpr int kUnroll = 6;       // iterations per unrolled loop body
-constexpr int kPrefetch = 6;     // rows in flight ahead of the pipeline (== kUnroll)
+constexpr int kPrefetch = 6;     // rows in flight ahead of the pipeline (divides every RING)
 constexpr int kTileCols = 128;   // columns per wave tile (2 per lane)
 
 constexpr int wrap3(int x) { return ((x % 3) + 3) % 3; }
+constexpr int wrapn(int x, int n) { return ((x % n) + n) % n; }
 constexpr bool is_even(int x) { return ((x % 2) + 2) % 2 == 0; }
-constexpr int ring_rows(int ns) { return ns + 1; }  // rows of d alive at once
+// rows of d alive at once (NS + 1), rounded up to a multiple of 6; also the unroll factor
+constexpr int ring_rows(int ns) { return ((ns + 1 + 5) / 6) * 6; }
 
 // Per-lane facts used only by tiles that touch the domain boundary.
 template <class B>
@@ -104,25 +108,35 @@ SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, t
     return out;
 }
 
-// The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U)
-// enters, row y - NS leaves.  U = (y - y_start) mod 6 is a compile-time constant.
-template <class B, int NS, bool EDGE, bool DX1, int U>
+// The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
+// enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int U>
 SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
-                    const EdgeCell<B> &ecb, int y, int ring_pos, int out_begin, int out_end)
+                    const EdgeCell<B> &ecb, int y, int out_begin, int out_end)
 {
     using V = typename B::V;
     constexpr int RING = ring_rows(NS);
+    constexpr int Q = U % kPrefetch;
 
     // ---- row y enters: hand it to version 0, park its d in the ring, refill the slot ----
     {
-        const V a = pp.pa[U], b = pp.pb[U];
-        const V fa = pp.da[U], fb = pp.db[U];
-        bk.load_row(y + kPrefetch, pp.pa[U], pp.pb[U], pp.da[U], pp.db[U]);
+        // detach(): an explicit register copy, so that the prefetch registers are free to
+        // receive the next load at once (otherwise the compiler keeps the old value alive in
+        // them and has to drain all loads in flight at the loop back-edge to rotate registers)
+        V a = bk.detach(pp.pa[Q]), b = bk.detach(pp.pb[Q]);
+        const V fa = pp.da[Q], fb = pp.db[Q];
+        bk.ring_store(U, 0, is_even(U) ? fa : fb);  // plane 0: d of the E cell
+        bk.ring_store(U, 1, is_even(U) ? fb : fa);  // plane 1: d of the O cell
+        bk.load_row(y + kPrefetch, pp.pa[Q], pp.pb[Q], pp.da[Q], pp.db[Q]);
+        if (ZERO_IN) a = b = bk.splat(0.0f);  // poisson.cpp:117-119, fused
+        if (EDGE) {  // cells outside the domain hold the additive identity
+            const RowFacts rf = bk.row_facts(y);
+            a = bk.select(bk.mask_and(eca.in, rf.in_dom), a, bk.splat(-0.0f));
+            b = bk.select(bk.mask_and(ecb.in, rf.in_dom), b, bk.splat(-0.0f));
+        }
         constexpr bool ev = is_even(U);
         pp.E[0][wrap3(U)] = ev ? a : b;
         pp.O[0][wrap3(U)] = ev ? b : a;
-        bk.ring_store(ring_pos, 0, ev ? fa : fb);  // plane 0: d of the E cell
-        bk.ring_store(ring_pos, 1, ev ? fb : fa);  // plane 1: d of the O cell
     }
 
 #pragma unroll
@@ -134,13 +148,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const int rel = U - lag;                 // compile time after unrolling
             const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
             const bool ev = is_even(rel);            // E cell is `a` in even rows
-            int rp = ring_pos - lag;
-            if (rp < 0) rp += RING;
             const V own = pp.E[m - 1][s0];
             const V oc = pp.O[m - 1][s0];
             const V w = ev ? bk.from_lower_lane(oc) : oc;
             const V e = ev ? oc : bk.from_upper_lane(oc);
-            const V d = bk.ring_load(rp, 0);
+            const V d = bk.ring_load(wrapn(rel, RING), 0);
             const RowFacts rf = bk.row_facts(r);
             pp.E[m][s0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[m - 1][sm], pp.O[m - 1][sp],
                                                d, ev ? eca : ecb, rf);
@@ -152,13 +164,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const int rel = U - lag;
             const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
             const bool ev = is_even(rel);            // O cell is `b` in even rows
-            int rp = ring_pos - lag;
-            if (rp < 0) rp += RING;
             const V own = pp.O[m - 1][s0];
             const V oc = pp.E[m][s0];
             const V w = ev ? oc : bk.from_lower_lane(oc);
             const V e = ev ? bk.from_upper_lane(oc) : oc;
-            const V d = bk.ring_load(rp, 1);
+            const V d = bk.ring_load(wrapn(rel, RING), 1);
             const RowFacts rf = bk.row_facts(r);
             const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[m][sm], pp.E[m][sp], d,
                                               ev ? ecb : eca, rf);
@@ -174,13 +184,22 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     }
 }
 
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int... Us>
+SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
+                         const EdgeCell<B> &ecb, int y, int out_begin, int out_end,
+                         std::integer_sequence<int, Us...>)
+{
+    (iterate<B, NS, EDGE, DX1, ZERO_IN, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end), ...);
+}
+
 // Stream one tile: output rows [out_begin, out_end), all NS passes.
-template <class B, int NS, bool EDGE, bool DX1>
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN>
 SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
                         const EdgeCell<B> &ecb, int out_begin, int out_end)
 {
     static_assert(NS >= 2 && NS % 2 == 0, "fuse an even number of colour passes");
     constexpr int RING = ring_rows(NS);
+    static_assert(RING % 6 == 0 && RING % kPrefetch == 0 && RING >= NS + 1, "ring geometry");
     Pipe<B, NS> pp;
     bk.poison(pp);  // no-op on the GPU; NaN-fills in the emulator to prove nothing stale leaks
 
@@ -193,19 +212,10 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 #pragma unroll
     for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
 
-    int ring_pos = 0;
     while (y < y_stop) {
-#define SFL_SOR_STEP(U)                                                                   \
-    iterate<B, NS, EDGE, DX1, U>(bk, pp, c, eca, ecb, y + U, ring_pos, out_begin, out_end); \
-    ring_pos = (ring_pos + 1 == RING) ? 0 : ring_pos + 1;
-        SFL_SOR_STEP(0)
-        SFL_SOR_STEP(1)
-        SFL_SOR_STEP(2)
-        SFL_SOR_STEP(3)
-        SFL_SOR_STEP(4)
-        SFL_SOR_STEP(5)
-#undef SFL_SOR_STEP
-        y += kUnroll;
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN>(bk, pp, c, eca, ecb, y, out_begin, out_end,
+                                                std::make_integer_sequence<int, RING>{});
+        y += RING;
     }
 }
 
@@ -242,9 +252,9 @@ SFL_HD bool tile_touches_boundary(const Tiling &t, int strip, int chunk, int gdi
     const int x0 = strip_x0(t, strip);
     const int r0 = t.g_begin + chunk * t.rows_per_chunk;
     const int r1 = (r0 + t.rows_per_chunk < t.g_end) ? r0 + t.rows_per_chunk : t.g_end;
-    // rows entering the pipeline: [r0 - ns - 1, r1 + ns + kUnroll); columns [x0, x0 + 128)
+    // rows entering the pipeline: [r0 - ns - 1, r1 + ns + ring); columns [x0, x0 + 128)
     return x0 <= 0 || x0 + kTileCols >= t.dim_x || r0 - t.ns - 1 <= 0 ||
-           r1 + t.ns + kUnroll >= gdim_y;
+           r1 + t.ns + ring_rows(t.ns) >= gdim_y;
 }
 
 }  // namespace sor

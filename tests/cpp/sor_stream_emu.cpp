@@ -100,30 +100,25 @@ struct EmuBackend {
         for (size_t k = 0; k < sizeof(P) / sizeof(float); ++k)
             f[k] = std::numeric_limits<float>::quiet_NaN();
     }
+    // Mirrors the GPU backend: loads are unconditional with clamped row / column.  To be
+    // stricter than the hardware, whatever a CLAMPED access would return is replaced by NaN:
+    // the pipeline must mask it (domain boundary) or keep it out of the exact interior.
     void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
         const bool row_ok = r >= row_lo && r < row_hi;
-        const bool in_dom = r >= 0 && r < gdim_y;
+        const float nan = std::numeric_limits<float>::quiet_NaN();
         for (int i = 0; i < 64; ++i) {
             const int xa = x0 + 2 * i;
             const bool a_in = xa >= 0 && xa < dim_x, b_in = xa + 1 >= 0 && xa + 1 < dim_x;
-            const float pdef = (in_dom && p_in == nullptr) ? 0.0f : -0.0f;
-            float va = a_in ? pdef : -0.0f, vb = b_in ? pdef : -0.0f, fa = 0.0f, fb = 0.0f;
-            if (row_ok) {
-                const size_t c = (size_t)(r - grow0) * dim_x + xa;
-                if (vec2 ? a_in : a_in) {
-                    fa = d[c];
-                    if (p_in) va = p_in[c];
-                }
-                if (vec2 ? a_in : b_in) {
-                    fb = d[c + 1];
-                    if (p_in) vb = p_in[c + 1];
-                }
+            const size_t c = row_ok ? (size_t)(r - grow0) * dim_x + xa : 0;
+            const bool a_ok = row_ok && (vec2 ? (a_in && b_in) : a_in);
+            const bool b_ok = row_ok && (vec2 ? (a_in && b_in) : b_in);
+            da.l[i] = a_ok ? d[c] : nan;
+            db.l[i] = b_ok ? d[c + 1] : nan;
+            if (p_in) {
+                pa.l[i] = a_ok ? p_in[c] : nan;
+                pb.l[i] = b_ok ? p_in[c + 1] : nan;
             }
-            pa.l[i] = va;
-            pb.l[i] = vb;
-            da.l[i] = fa;
-            db.l[i] = fb;
         }
     }
     void store_row(int r, const V &a, const V &b) const
@@ -148,6 +143,7 @@ struct EmuBackend {
         std::memcpy(r.l, &ring[(size_t)(slot * 2 + plane) * 64], sizeof(r.l));
         return r;
     }
+    V detach(const V &x) const { return x; }
 };
 
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
@@ -196,13 +192,16 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
             const bool edge = force_edge || tile_touches_boundary(t, strip, chunk, gdim_y);
             const bool dx1 = dx == 1.0f;
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
+            const bool zero_in = p_in == nullptr;
+#define EMU_RUN(EDGE, DX1, ZERO) stream_tile<EmuBackend, NS, EDGE, DX1, ZERO>(bk, c, eca, ecb, r0, r1)
             if (edge) {
-                if (dx1) stream_tile<EmuBackend, NS, true, true>(bk, c, eca, ecb, r0, r1);
-                else stream_tile<EmuBackend, NS, true, false>(bk, c, eca, ecb, r0, r1);
+                if (dx1) { if (zero_in) EMU_RUN(true, true, true); else EMU_RUN(true, true, false); }
+                else     { if (zero_in) EMU_RUN(true, false, true); else EMU_RUN(true, false, false); }
             } else {
-                if (dx1) stream_tile<EmuBackend, NS, false, true>(bk, c, eca, ecb, r0, r1);
-                else stream_tile<EmuBackend, NS, false, false>(bk, c, eca, ecb, r0, r1);
+                if (dx1) { if (zero_in) EMU_RUN(false, true, true); else EMU_RUN(false, true, false); }
+                else     { if (zero_in) EMU_RUN(false, false, true); else EMU_RUN(false, false, false); }
             }
+#undef EMU_RUN
         }
     }
 }

@@ -1,0 +1,98 @@
+"""CPU suite: the PRODUCT's fused SOR pipeline (csrc/sor_stream_core.h, the header the GPU kernel
+is compiled from) executed lane-by-lane by tests/cpp/sor_stream_emu.cpp and compared with the
+oracle bit for bit.  Pipeline registers, the LDS ring and every clamped load are NaN-poisoned
+in the emulator, so a stale or out-of-tile read cannot go unnoticed."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bit_equal
+
+OMEGA = np.float32(1.96)
+_F = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    d = os.path.join(ROOT, "tests", "cpp")
+    so = os.path.join(d, "libsor_stream_emu.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
+    lib.emu_sor_fused.restype = C.c_int
+
+    def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None):
+        lrows, dim_x = d.shape
+        gdim_y = lrows if gdim_y is None else gdim_y
+        g_end = gdim_y if g_end is None else g_end
+        out = np.full_like(d, np.nan) if out is None else out
+        fp = lambda a: None if a is None else a.ctypes.data_as(_F)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0)
+        rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
+                               ns, dx, omega, rows, flags)
+        assert rc == 0
+        return out
+    return run
+
+
+SHAPES = [(2, 2), (3, 3), (5, 4), (61, 81), (64, 48), (130, 70), (300, 41), (257, 100)]
+
+
+@pytest.mark.parametrize("dim_x,dim_y", SHAPES)
+@pytest.mark.parametrize("ns", [2, 4, 6, 8, 12, 16])
+def test_fused_passes_from_zero(emu, oracle, dim_x, dim_y, ns):
+    d = np.random.default_rng(dim_x * 1000 + dim_y).standard_normal((dim_y, dim_x)).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, ns // 2, OMEGA)
+    assert_bit_equal(emu(None, d, ns, rows=16), want, "auto edge")
+    assert_bit_equal(emu(None, d, ns, rows=40, force_edge=True), want, "forced edge path")
+    if dim_x % 2 == 0:
+        assert_bit_equal(emu(None, d, ns, rows=16, vec2=True), want, "vec2 access variant")
+
+
+@pytest.mark.parametrize("dim_x,dim_y", SHAPES)
+@pytest.mark.parametrize("ns", [2, 8, 10, 14])
+def test_fused_passes_continue(emu, oracle, dim_x, dim_y, ns):
+    rng = np.random.default_rng(7)
+    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    assert_bit_equal(emu(p0, d, ns, rows=24), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "continue")
+    assert_bit_equal(emu(p0, d, ns, rows=24, dx=0.5, omega=np.float32(1.4)),
+                     oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "dx, omega")
+
+
+def test_signed_zero_fields(emu, oracle):
+    for fill in (0.0, -0.0):
+        d = np.full((30, 140), fill, np.float32)
+        d[5, 7] = 2.0
+        assert_bit_equal(emu(None, d, 4), oracle.poisson_solve(d, 1.0, 2, OMEGA), f"fill {fill}")
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("ns", [4, 8])
+def test_slab_launch_matches_whole_domain(emu, oracle, nranks, ns):
+    """One fused launch on a slab (local array with ghost rows, global row offset) produces the
+    slab's rows of the whole-domain result, given valid input on own +- ns rows."""
+    dim_x, dim_y, ghost = 150, 96, 16
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    want = oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA)
+    for r in range(nranks):
+        g0, g1 = dim_y * r // nranks, dim_y * (r + 1) // nranks
+        grow0 = g0 - ghost
+        lo, hi = max(grow0, 0), min(g1 + ghost, dim_y)
+        # local arrays: NaN everywhere except the rows a halo exchange would have delivered
+        def local(a, halo):
+            l = np.full((g1 - g0 + 2 * ghost, dim_x), np.nan, np.float32)
+            a0, a1 = max(g0 - halo, 0), min(g1 + halo, dim_y)
+            l[a0 - grow0:a1 - grow0] = a[a0:a1]
+            return l
+        out = np.full((g1 - g0 + 2 * ghost, dim_x), np.nan, np.float32)
+        emu(local(p0, ns), local(d, ns - 1), ns, rows=20, gdim_y=dim_y, grow0=grow0, g_begin=g0,
+            g_end=g1, out=out)
+        assert_bit_equal(out[g0 - grow0:g1 - grow0], want[g0:g1], f"slab {r}/{nranks}")
