@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=0, help="SOR half-sweeps fused per launch (0 = library default)")
     ap.add_argument("--sor-kernel", type=int, default=0)
     ap.add_argument("--sor-rows", type=int, default=0)
+    ap.add_argument("--lane-cells", type=int, default=0, help="cells per lane of the fused kernel (0 auto, 2, 4)")
     ap.add_argument("--sim-steps", type=int, default=3, help="full sim steps timed after the main region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -128,6 +129,8 @@ def main():
         s.set_option(capi.OPT_SOR_KERNEL, args.sor_kernel)
     if args.sor_rows:
         s.set_option(capi.OPT_SOR_ROWS, args.sor_rows)
+    if args.lane_cells:
+        s.set_option(capi.OPT_SOR_LANE_CELLS, args.lane_cells)
     if world > 1:
         uid = [sfl.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libsfl_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_RCCL, ERR_NOMEM, ERR_STATE, ERR_HALO = 0, -1, -2, -3, -4, -5, -6
 FIELD_VELOCITY, FIELD_COLOR, FIELD_DIVERGENCE, FIELD_PRESSURE = 0, 1, 2, 3
 OPT_SOR_KERNEL, OPT_SOR_FUSE, OPT_ADVECT_HALO, OPT_SOR_ROWS, OPT_TRANSPORT = 0, 1, 2, 3, 4
+OPT_SOR_LANE_CELLS = 5
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 

@@ -100,8 +100,8 @@ struct sfl_context {
     float *d_force_vel = nullptr;
     int d_force_cap = 0;
 
-    int opt_sor_kernel = 0, opt_sor_fuse = 8, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_transport = 0;
+    int opt_sor_kernel = 0, opt_sor_fuse = 16, opt_advect_halo = 4, opt_sor_rows = 0,
+        opt_transport = 0, opt_sor_lane_cells = 0;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -283,7 +283,7 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
     SFL_TRY(ensure(c, c->p_alt, 4, false));
     HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
                                   c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
-                                  c->opt_sor_rows));
+                                  c->opt_sor_rows, c->opt_sor_lane_cells));
     std::swap(c->p, c->p_alt);
     ++c->last_launches;
     return SFL_OK;
@@ -527,6 +527,11 @@ int sfl_set_option(sfl_context *c, int option, int value)
         case SFL_OPT_TRANSPORT:
             c->opt_transport = value;
             return SFL_OK;
+        case SFL_OPT_SOR_LANE_CELLS:
+            if (value != 0 && value != 2 && value != 4)
+                return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto), 2 or 4");
+            c->opt_sor_lane_cells = value;
+            return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -540,6 +545,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_ADVECT_HALO: *value = c->opt_advect_halo; return SFL_OK;
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
         case SFL_OPT_TRANSPORT: *value = c->opt_transport; return SFL_OK;
+        case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -886,6 +892,8 @@ int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, flo
     if (k) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_KERNEL, atoi(k)));
     const char *f = getenv("SFL_SOR_FUSE");
     if (f) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_FUSE, atoi(f)));
+    const char *l = getenv("SFL_SOR_LANE_CELLS");
+    if (l) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_LANE_CELLS, atoi(l)));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4));
     SFL_TRY(sfl_poisson_solve(t.c, dx, iters, omega));
     return sfl_download(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4);

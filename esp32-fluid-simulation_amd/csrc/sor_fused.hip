@@ -1,10 +1,17 @@
-// sor_fused.hip -- gfx950 backend + launcher of the fused red-black SOR pipeline
+// sor_fused.hip -- gfx950 backends + launcher of the fused red-black SOR pipeline
 // (sor_stream_core.h).  One 64-lane wavefront streams one tile; lanes exchange their W / E
-// neighbours with DPP wave shifts (folded into v_add_f32_dpp), S / N neighbours stay in
-// VGPRs, the right-hand side waits in a per-lane LDS ring.  No barriers, no atomics, no MFMA:
-// this is a bandwidth / VALU-issue bound stencil.
+// neighbours with DPP wave shifts, S / N neighbours stay in VGPRs, the right-hand side waits in
+// a per-lane LDS ring.  No barriers, no atomics, no MFMA: a bandwidth / VALU-issue bound stencil.
 //
-// Compiled with -ffp-contract=off (bit-exactness contract, see stencil_kernels.hip).
+// Two lane flavours:
+//   Lane2  2 cells per lane, V = float, 128-column tiles, 4- or 8-byte accesses; works for every
+//          dim_x (odd widths use dword accesses) -- the general path
+//   Lane4  4 cells per lane, V = 2 packed floats, 256-column tiles, 16-byte accesses, every
+//          relaxation in packed fp32 (v_pk_add_f32 / v_pk_mul_f32): twice the arithmetic
+//          throughput, half the tile overlap; needs dim_x % 4 == 0 and 16-byte aligned arrays
+//
+// Compiled with -ffp-contract=off (bit-exactness contract, see stencil_kernels.hip); packed
+// add / mul round each component separately, exactly like the scalar instructions.
 #include "kernels.h"
 #include "sor_stream_core.h"
 
@@ -15,7 +22,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = 64 * kWavesPerBlock;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // DPP full-wave shifts (GFX9 wave_shr:1 / wave_shl:1).  Lane 0 / lane 63 receive 0, which only
 // ever feeds cells of the tile's invalid rim.
@@ -30,31 +39,76 @@ __device__ __forceinline__ float lane_above(float x)  // value of lane + 1
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
 }
 
-// VEC2: dim_x even and all base pointers 8-byte aligned -> one 8-byte access per lane and row.
-// ZERO_IN: p is implicitly zero on entry (first launch of a solve): p is never read.
-//
-// Loads are UNCONDITIONAL and branch-free: the row index is clamped into the rows the local
-// array holds and the lane's column into the domain, so every address is valid; what a
-// clamped access returns is irrelevant -- cells outside the domain are overwritten with -0.0f
-// when they enter the pipeline (EDGE tiles), and clamped rows only ever feed rows outside the
-// tile's exact interior.  This keeps the prefetched rows in flight across iterations (a guarded
-// load would have to be waited for inside its branch).
-template <int NS, bool VEC2, bool ZERO_IN>
-struct WaveBackend {
+// State shared by both flavours.  Loads are UNCONDITIONAL and branch-free: the row index is
+// clamped into the rows the local array holds and the lane's column into the domain, so every
+// address is valid; what a clamped access returns is irrelevant -- cells outside the domain are
+// overwritten with -0.0f when they enter the pipeline (EDGE tiles), and clamped rows only ever
+// feed rows outside the tile's exact interior.  This keeps the prefetched rows in flight across
+// iterations (a guarded load would have to be waited for inside its branch).  Addresses are a
+// per-lane byte offset (loop invariant VGPR) plus a wave-uniform row offset (SGPR) into a buffer
+// resource: no address arithmetic on the vector ALU.
+struct WaveCommon {
+    __amdgpu_buffer_rsrc_t rs_p, rs_d, rs_out;
+    int dim_x, gdim_y;
+    int grow0;           // global row of local row 0
+    int row_lo, row_hi;  // global rows present in the local arrays AND inside the domain
+
+    __device__ __forceinline__ sor::RowFacts row_facts(int r) const
+    {
+        return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
+    }
+    template <class P>
+    __device__ __forceinline__ void poison(P &) const {}
+    __device__ __forceinline__ int row_bytes(int r) const { return (r - grow0) * dim_x * 4; }
+    __device__ __forceinline__ int load_row_bytes(int r) const
+    {
+        return row_bytes(min(max(r, row_lo), row_hi - 1));
+    }
+};
+
+// ---- 2 cells per lane --------------------------------------------------------------------
+// VEC: dim_x even and 8-byte aligned arrays -> one 8-byte access per lane and row.
+template <int NS, bool VEC, bool ZERO_IN>
+struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
-    static constexpr int RING = sor::ring_rows(NS);
+    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6;
+    static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
-    // buffer resources (base = local row 0 of each array): loads / stores take a per-lane byte
-    // offset (loop invariant) plus a wave-uniform row offset in an SGPR -- no address VALU
-    __amdgpu_buffer_rsrc_t rs_p, rs_d, rs_out;
-    float *ring;            // this lane's word of ring slot 0 / plane 0 in LDS
-    int dim_x, gdim_y;
-    int grow0;              // global row of local row 0
-    int row_lo, row_hi;     // global rows present in the local arrays AND inside the domain
-    int off_a, off_b;       // byte offsets of the clamped load columns of cell a / b
-    int off_out;            // byte offset of the true column of cell a
-    bool a_out, b_out;      // columns this tile is responsible for (valid interior, in the domain)
+    float *ring;         // this lane's word of ring slot 0 / plane 0 in LDS
+    int off_a, off_b;    // byte offsets of the clamped load columns of cell a / b
+    int off_out;         // byte offset of the true column of cell a
+    bool a_out, b_out;   // columns this tile is responsible for (exact interior, in the domain)
+
+    __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
+    {
+        ring = ring_base + lane;
+        const int xa = x0 + 2 * lane;
+        if (VEC) {  // dim_x even: the pair is inside or outside as a whole
+            off_a = 4 * min(max(xa, 0), dim_x - 2);
+            off_b = off_a + 4;
+        } else {
+            off_a = 4 * min(max(xa, 0), dim_x - 1);
+            off_b = 4 * min(max(xa + 1, 0), dim_x - 1);
+        }
+        off_out = 4 * xa;
+        const int out_lo = x0 + halo, out_hi = x0 + kTileCols - halo;
+        a_out = xa >= 0 && xa < dim_x && xa >= out_lo && xa < out_hi;
+        b_out = xa + 1 >= 0 && xa + 1 < dim_x && xa + 1 >= out_lo && xa + 1 < out_hi;
+    }
+    __device__ __forceinline__ sor::EdgeCell<Lane2> edge_cell(int lane, int x0, int which) const
+    {
+        const int x = x0 + 2 * lane + which;
+        sor::EdgeCell<Lane2> ec;
+        const int nh = (x > 0 ? 1 : 0) + (x < dim_x - 1 ? 1 : 0);  // horizontal neighbours present
+        // -1/n evaluated in double and narrowed, poisson.cpp:67
+        const float k2 = (float)(-1.0 / 2.0), k3 = (float)(-1.0 / 3.0), k4 = -0.25f;
+        ec.in = x >= 0 && x < dim_x;
+        ec.k_full = (nh == 2) ? k4 : (nh == 1) ? k3 : k2;
+        ec.k_part = (nh == 2) ? k3 : k2;  // nh == 0 only when dim_x == 1 (rejected by the API)
+        ec.z_full = (nh == 2) ? -0.0f : 0.0f;
+        return ec;
+    }
 
     __device__ __forceinline__ V splat(float x) const { return x; }
     __device__ __forceinline__ V select(M m, V a, V b) const { return m ? a : b; }
@@ -67,22 +121,11 @@ struct WaveBackend {
         asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
         return r;
     }
-    __device__ __forceinline__ sor::RowFacts row_facts(int r) const
-    {
-        return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
-    }
-    template <class P>
-    __device__ __forceinline__ void poison(P &) const {}
-
-    __device__ __forceinline__ int row_bytes(int r) const  // wave-uniform
-    {
-        return (r - grow0) * dim_x * 4;
-    }
 
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
-        const int soff = row_bytes(min(max(r, row_lo), row_hi - 1));
-        if (VEC2) {
+        const int soff = load_row_bytes(r);
+        if (VEC) {
             const v2f f = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, soff, 0));
             da = f.x;
             db = f.y;
@@ -91,7 +134,7 @@ struct WaveBackend {
             db = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, off_b, soff, 0));
         }
         if (!ZERO_IN) {
-            if (VEC2) {
+            if (VEC) {
                 const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, 0));
                 pa = q.x;
                 pb = q.y;
@@ -105,7 +148,7 @@ struct WaveBackend {
     __device__ __forceinline__ void store_row(int r, V a, V b) const
     {
         const int soff = row_bytes(r);
-        if (VEC2) {
+        if (VEC) {
             if (a_out) {
                 v2f o;
                 o.x = a;
@@ -130,33 +173,124 @@ struct WaveBackend {
     }
 };
 
-template <class B>
-__device__ __forceinline__ sor::EdgeCell<B> edge_cell(int x, int dim_x)
-{
-    sor::EdgeCell<B> ec;
-    const bool in = x >= 0 && x < dim_x;
-    const int nh = (x > 0 ? 1 : 0) + (x < dim_x - 1 ? 1 : 0);  // horizontal neighbours present
-    // -1/n evaluated in double and narrowed, poisson.cpp:67
-    const float k2 = (float)(-1.0 / 2.0), k3 = (float)(-1.0 / 3.0), k4 = -0.25f;
-    ec.in = in;
-    ec.k_full = (nh == 2) ? k4 : (nh == 1) ? k3 : k2;
-    ec.k_part = (nh == 2) ? k3 : k2;  // nh == 0 only when dim_x == 1 (rejected by the API)
-    ec.z_full = (nh == 2) ? -0.0f : 0.0f;
-    return ec;
-}
+// ---- 4 cells per lane, packed fp32 ----------------------------------------------------------
+struct Mask2 {
+    bool x, y;
+};
 
-template <int NS, bool VEC2, bool DX1, bool ZERO_IN>
+template <int NS, bool ZERO_IN>
+struct Lane4 : WaveCommon {
+    using V = v2f;
+    using M = Mask2;
+    static constexpr int kTileCols = 256, kColAlign = 4, kCells = 4, kPrefetch = 3;
+    static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 128;
+
+    v2f *ring;        // this lane's pair of ring slot 0 / plane 0 in LDS
+    int off_in;       // byte offset of the clamped load column of the lane's first cell
+    int off_out;      // byte offset of its true column
+    bool quad_out;    // the lane's four columns lie in the tile's exact interior and the domain
+
+    __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
+    {
+        ring = reinterpret_cast<v2f *>(ring_base) + lane;
+        const int xq = x0 + 4 * lane;  // multiple of 4; dim_x % 4 == 0: quad inside or outside
+        off_in = 4 * min(max(xq, 0), dim_x - 4);
+        off_out = 4 * xq;
+        quad_out = xq >= 0 && xq < dim_x && xq >= x0 + halo && xq < x0 + kTileCols - halo;
+    }
+    // which = 0: cells a = columns {xq, xq + 2}; which = 1: cells b = {xq + 1, xq + 3}
+    __device__ __forceinline__ sor::EdgeCell<Lane4> edge_cell(int lane, int x0, int which) const
+    {
+        sor::EdgeCell<Lane4> ec;
+        const float k2 = (float)(-1.0 / 2.0), k3 = (float)(-1.0 / 3.0), k4 = -0.25f;
+        float kf[2], kp[2], zf[2];
+        bool in[2];
+        for (int c = 0; c < 2; ++c) {
+            const int x = x0 + 4 * lane + which + 2 * c;
+            const int nh = (x > 0 ? 1 : 0) + (x < dim_x - 1 ? 1 : 0);
+            in[c] = x >= 0 && x < dim_x;
+            kf[c] = (nh == 2) ? k4 : (nh == 1) ? k3 : k2;
+            kp[c] = (nh == 2) ? k3 : k2;
+            zf[c] = (nh == 2) ? -0.0f : 0.0f;
+        }
+        ec.in = {in[0], in[1]};
+        ec.k_full = v2f{kf[0], kf[1]};
+        ec.k_part = v2f{kp[0], kp[1]};
+        ec.z_full = v2f{zf[0], zf[1]};
+        return ec;
+    }
+
+    __device__ __forceinline__ V splat(float x) const { return v2f{x, x}; }
+    __device__ __forceinline__ V select(M m, V a, V b) const
+    {
+        return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y};
+    }
+    __device__ __forceinline__ M mask_and(M m, bool row) const { return {m.x && row, m.y && row}; }
+    // colour vector shifted by one position: {previous lane's .y, own .x} / {own .y, next lane's .x}
+    __device__ __forceinline__ V from_lower_lane(V v) const { return v2f{lane_below(v.y), v.x}; }
+    __device__ __forceinline__ V from_upper_lane(V v) const { return v2f{v.y, lane_above(v.x)}; }
+    __device__ __forceinline__ V detach(V v) const
+    {
+        V r;
+        asm("v_mov_b32 %0, %1" : "=v"(r.x) : "v"(v.x));
+        asm("v_mov_b32 %0, %1" : "=v"(r.y) : "v"(v.y));
+        return r;
+    }
+
+    __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
+    {
+        const int soff = load_row_bytes(r);
+        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off_in, soff, 0));
+        da = v2f{f.x, f.z};
+        db = v2f{f.y, f.w};
+        if (!ZERO_IN) {
+            const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off_in, soff, 0));
+            pa = v2f{q.x, q.z};
+            pb = v2f{q.y, q.w};
+        }
+    }
+
+    __device__ __forceinline__ void store_row(int r, V a, V b) const
+    {
+        if (quad_out) {
+            const v4f o = {a.x, b.x, a.y, b.y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, o), rs_out, off_out, row_bytes(r), 0);
+        }
+    }
+
+    // ring: [RING slots][2 planes][64 lanes] of float pairs (8-byte DS accesses, conflict free)
+    __device__ __forceinline__ void ring_store(int slot, int plane, V x) const
+    {
+        ring[(slot * 2 + plane) * 64] = x;
+    }
+    __device__ __forceinline__ V ring_load(int slot, int plane) const
+    {
+        return ring[(slot * 2 + plane) * 64];
+    }
+};
+
+template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads)
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t,
                  SorParams prm)
 {
-    using B = WaveBackend<NS, VEC2, ZERO_IN>;
-    __shared__ float ring_mem[kWavesPerBlock][B::RING * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
 
     // everything derived from the wave index is wave-uniform: tell the compiler (SGPRs)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    // XCD-aware block order: the dispatcher deals consecutive blocks round-robin to the 8 XCDs
+    // (each with a private L2); give every XCD a CONTIGUOUS range of tiles instead, so that
+    // horizontally / vertically adjacent tiles -- which re-read each other's halo columns and
+    // rows -- hit in the same L2.  Speed only: any placement computes the same result.
+    const int nblocks = gridDim.x;
+    int block = blockIdx.x;
+    {
+        const int per = nblocks >> 3, rem = nblocks & 7;
+        const int xcd = block & 7, idx = block >> 3;
+        block = xcd * per + min(xcd, rem) + idx;  // bijective for every nblocks
+    }
+    const int tile = block * kWavesPerBlock + wave;
     if (tile >= t.n_strips * t.n_chunks) return;
     const int chunk = tile / t.n_strips;
     const int strip = tile - chunk * t.n_strips;
@@ -171,32 +305,18 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
     bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
     bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
-    bk.ring = &ring_mem[wave][lane];
     bk.dim_x = g.dim_x;
     bk.gdim_y = g.gdim_y;
     bk.grow0 = g.grow0;
     bk.row_lo = max(g.grow0, 0);
     bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
-    const int xa = x0 + 2 * lane;  // true column of cell a (even; may be < 0 or >= dim_x)
-    const bool a_in = xa >= 0 && xa < g.dim_x;
-    const bool b_in = xa + 1 >= 0 && xa + 1 < g.dim_x;
-    if (VEC2) {  // dim_x even: the pair is inside or outside as a whole
-        bk.off_a = 4 * min(max(xa, 0), g.dim_x - 2);
-        bk.off_b = bk.off_a + 4;
-    } else {
-        bk.off_a = 4 * min(max(xa, 0), g.dim_x - 1);
-        bk.off_b = 4 * min(max(xa + 1, 0), g.dim_x - 1);
-    }
-    bk.off_out = 4 * xa;
-    const int out_lo = x0 + NS, out_hi = x0 + sor::kTileCols - NS;
-    bk.a_out = a_in && xa >= out_lo && xa < out_hi;
-    bk.b_out = b_in && xa + 1 >= out_lo && xa + 1 < out_hi;
+    bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
 
-    sor::Consts<B> c{prm.dx, prm.omega, prm.one_minus_omega};
+    sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
 
     if (sor::tile_touches_boundary(t, strip, chunk, g.gdim_y)) {  // wave-uniform
-        const auto eca = edge_cell<B>(xa, g.dim_x);
-        const auto ecb = edge_cell<B>(xa + 1, g.dim_x);
+        const auto eca = bk.edge_cell(lane, x0, 0);
+        const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
     } else {
         const sor::EdgeCell<B> none{};
@@ -204,66 +324,152 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     }
 }
 
-template <int NS>
-hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     const sor::Tiling &t, SorParams prm)
+// Resident waves of one instantiation on the whole device (occupancy query, cached).
+template <class B, int NS, bool DX1, bool ZERO_IN>
+int resident_waves()
 {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0, cus = 0, blocks = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, sor_fused_kernel<B, NS, DX1, ZERO_IN>,
+                                                     kThreads, 0) != hipSuccess ||
+        blocks < 1 || cus < 1) {
+        (void)hipGetLastError();
+        return 256 * 4 * 3;  // not cached: try again next time
+    }
+    cached = cus * blocks * kWavesPerBlock;
+    return cached;
+}
+
+// Output rows per wave tile: every tile costs the same, so the launch takes
+// ceil(tiles / resident waves) rounds; pick the chunk count that fills whole rounds with the
+// fewest rows of warm-up overhead (each chunk re-streams 2 * NS extra rows).
+inline int auto_rows_per_chunk(int rows, int strips, int ns, int waves)
+{
+    int best_rows = rows;
+    double best_cost = 1e300;
+    const int max_chunks = (rows + 15) / 16;
+    for (int chunks = 1; chunks <= max_chunks; ++chunks) {
+        const int rpc = (rows + chunks - 1) / chunks;
+        const int real_chunks = (rows + rpc - 1) / rpc;
+        const long tiles = (long)real_chunks * strips;
+        const long rounds = (tiles + waves - 1) / waves;
+        const double cost = (double)rounds * (rpc + 2 * ns + 2);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best_rows = rpc;
+        }
+        if (tiles > 8L * waves) break;
+    }
+    return best_rows;
+}
+
+template <class B, int NS, bool DX1, bool ZERO_IN>
+hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
+                          int g_begin, int g_end, SorParams prm, int rows_per_chunk)
+{
+    sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g_begin, g_end, 1);
+    const int rpc = rows_per_chunk > 0
+                        ? rows_per_chunk
+                        : auto_rows_per_chunk(g_end - g_begin, t.n_strips, NS,
+                                              resident_waves<B, NS, DX1, ZERO_IN>());
+    t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g_begin, g_end, rpc);
     const int tiles = t.n_strips * t.n_chunks;
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const bool aligned = (g.dim_x % 2 == 0) && ((reinterpret_cast<uintptr_t>(p_out) & 7) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(p_in) & 7) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(d) & 7) == 0);
-    const bool dx1 = prm.dx == 1.0f;
-#define SFL_LAUNCH(VEC2, DX1)                                                                  \
-    do {                                                                                       \
-        if (p_in)                                                                              \
-            sor_fused_kernel<NS, VEC2, DX1, false><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm); \
-        else                                                                                   \
-            sor_fused_kernel<NS, VEC2, DX1, true><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);  \
-    } while (0)
-    if (aligned) {
-        if (dx1) SFL_LAUNCH(true, true); else SFL_LAUNCH(true, false);
-    } else {
-        if (dx1) SFL_LAUNCH(false, true); else SFL_LAUNCH(false, false);
-    }
-#undef SFL_LAUNCH
+    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
     return hipGetLastError();
+}
+
+template <class B, int NS, bool ZERO_IN>
+hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
+                     int g_begin, int g_end, SorParams prm, int rows_per_chunk)
+{
+    if (prm.dx == 1.0f)
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+}
+
+template <int NS, bool ZERO_IN>
+hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
+                       int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
+{
+    const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
+                          reinterpret_cast<uintptr_t>(d);
+    const bool can4 = (g.dim_x % 4 == 0) && (all & 15) == 0 && g.dim_x >= 4;
+    const bool can2v = (g.dim_x % 2 == 0) && (all & 7) == 0;
+    // auto: the scalar flavour (4 waves / SIMD at fuse 8..12, 3 at 16) measured equal or faster
+    // than the packed one at every fuse depth on 8192^2 (profiles/r01_*); packed is opt-in
+    if (lane_cells == 0) lane_cells = 2;
+    if (lane_cells == 4 && can4)
+        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    if (can2v)
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+}
+
+template <int NS>
+hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
+                     int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
+{
+    if (p_in == nullptr)
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
 }
 
 }  // namespace
 
+// One non-template entry per fuse depth; the depths are spread over several translation units
+// (SFL_NS_GROUP = 0..3, see csrc/Makefile) so that they compile in parallel.
+#ifndef SFL_NS_GROUP
+#define SFL_NS_GROUP (-1)  // single translation unit: everything
+#endif
+#define SFL_DEFINE_NS(N)                                                                          \
+    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
+                                      Slab g, int g_begin, int g_end, SorParams prm,              \
+                                      int rows_per_chunk, int lane_cells)                         \
+    {                                                                                             \
+        return launch_ns<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells); \
+    }
+#define SFL_DECLARE_NS(N)                                                                         \
+    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
+                                      Slab g, int g_begin, int g_end, SorParams prm,              \
+                                      int rows_per_chunk, int lane_cells);
+SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
+SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
+#if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(2) SFL_DEFINE_NS(4) SFL_DEFINE_NS(6)
+#endif
+#if SFL_NS_GROUP == 1 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(8) SFL_DEFINE_NS(10)
+#endif
+#if SFL_NS_GROUP == 2 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(12) SFL_DEFINE_NS(14)
+#endif
+#if SFL_NS_GROUP == 3 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(16)
+#endif
+
+#if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk)
+                            SorParams prm, int rows_per_chunk, int lane_cells)
 {
     if (g_end <= g_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
-        p_out == p_in || p_out == nullptr || d == nullptr)
+        p_out == p_in || p_out == nullptr || d == nullptr ||
+        (lane_cells != 0 && lane_cells != 2 && lane_cells != 4))
         return hipErrorInvalidValue;
-    if (rows_per_chunk <= 0) {
-        // enough tiles to fill 256 CUs x 4 SIMDs a few times over, but chunks long enough
-        // that the 2*NS warm-up rows stay a small fraction
-        const int strips = (g.dim_x + sor::strip_step(nsweeps) - 1) / sor::strip_step(nsweeps);
-        const int rows = g_end - g_begin;
-        int want_chunks = (256 * 4 * 4 + strips - 1) / strips;
-        if (want_chunks < 1) want_chunks = 1;
-        rows_per_chunk = (rows + want_chunks - 1) / want_chunks;
-        const int min_rows = 8 * nsweeps;
-        if (rows_per_chunk < min_rows) rows_per_chunk = min_rows;
-        if (rows_per_chunk > rows) rows_per_chunk = rows;
-    }
-    const sor::Tiling t = sor::make_tiling(nsweeps, g.dim_x, g_begin, g_end, rows_per_chunk);
+    if (rows_per_chunk > g_end - g_begin) rows_per_chunk = g_end - g_begin;
+#define SFL_CASE(N) \
+    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
     switch (nsweeps) {
-        case 2: return launch_ns<2>(s, p_out, p_in, d, g, t, prm);
-        case 4: return launch_ns<4>(s, p_out, p_in, d, g, t, prm);
-        case 6: return launch_ns<6>(s, p_out, p_in, d, g, t, prm);
-        case 8: return launch_ns<8>(s, p_out, p_in, d, g, t, prm);
-        case 10: return launch_ns<10>(s, p_out, p_in, d, g, t, prm);
-        case 12: return launch_ns<12>(s, p_out, p_in, d, g, t, prm);
-        case 14: return launch_ns<14>(s, p_out, p_in, d, g, t, prm);
-        case 16: return launch_ns<16>(s, p_out, p_in, d, g, t, prm);
+        SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }
+#undef SFL_CASE
     return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace sfl

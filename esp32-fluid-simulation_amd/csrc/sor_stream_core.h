@@ -9,8 +9,13 @@
 // poisson.cpp:14-112 on one tile, in ONE sweep over the tile's rows, reading p and d once
 // and writing p once.  Bit-identical to running the passes one after the other.
 //
-// Tile = 128 columns (2 per lane: cell `a` at an even column x_a, cell `b` at x_a + 1)
-// x a run of rows streamed bottom-up.  Colours: a cell is "E" when (column + row) is even
+// Tile = 64 lanes x (2 or 4) columns x a run of rows streamed bottom-up.  A lane's value type
+// V holds its cells of ONE colour in a row: with 2 cells per lane V = float (cell `a` at an even
+// column x_a, cell `b` at x_a + 1); with 4 cells per lane V = two packed floats, a = {x_a,
+// x_a + 2}, b = {x_a + 1, x_a + 3}, and every relaxation is carried out with packed fp32
+// instructions (plain fp32 VALU ops issue at 4 cycles per wave on gfx950, packed ones process
+// two floats per lane in the same 4 cycles).  from_lower_lane / from_upper_lane shift a
+// colour vector by one position of that colour towards higher / lower columns.  Colours: a cell is "E" when (column + row) is even
 // (updated by the first pass of an iteration, poisson.cpp:22) and "O" otherwise.  In a row of
 // even parity the E cell of a lane is `a`, in an odd row it is `b`.
 //
@@ -46,8 +51,6 @@
 namespace sfl {
 namespace sor {
 
-constexpr int kPrefetch = 6;     // rows in flight ahead of the pipeline (divides every RING)
-constexpr int kTileCols = 128;   // columns per wave tile (2 per lane)
 
 constexpr int wrap3(int x) { return ((x % 3) + 3) % 3; }
 constexpr int wrapn(int x, int n) { return ((x % n) + n) % n; }
@@ -75,13 +78,14 @@ struct Consts {
     typename B::V dx, omega, one_minus_omega;
 };
 
+// B::kPrefetch = rows in flight ahead of the pipeline (must divide 6, hence every RING)
 template <class B, int NS>
 struct Pipe {
     using V = typename B::V;
     V E[NS / 2 + 1][3];
     V O[NS / 2 + 1][3];             // O[NS/2] is never stored (written straight to memory)
-    V pa[kPrefetch], pb[kPrefetch];  // prefetched p rows (cell a / cell b)
-    V da[kPrefetch], db[kPrefetch];  // prefetched d rows
+    V pa[B::kPrefetch], pb[B::kPrefetch];  // prefetched p rows (cell a / cell b)
+    V da[B::kPrefetch], db[B::kPrefetch];  // prefetched d rows
 };
 
 // One relaxation (poisson.cpp:63-112).
@@ -116,6 +120,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
 {
     using V = typename B::V;
     constexpr int RING = ring_rows(NS);
+    constexpr int kPrefetch = B::kPrefetch;
     constexpr int Q = U % kPrefetch;
 
     // ---- row y enters: hand it to version 0, park its d in the ring, refill the slot ----
@@ -189,7 +194,11 @@ SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeC
                          const EdgeCell<B> &ecb, int y, int out_begin, int out_end,
                          std::integer_sequence<int, Us...>)
 {
-    (iterate<B, NS, EDGE, DX1, ZERO_IN, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end), ...);
+    // rows at or beyond y_stop need not enter: leave the unrolled body early on the last trip
+    const int y_stop = out_end + NS;
+    (void)((y + Us < y_stop &&
+            (iterate<B, NS, EDGE, DX1, ZERO_IN, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end),
+             true)) && ...);
 }
 
 // Stream one tile: output rows [out_begin, out_end), all NS passes.
@@ -199,7 +208,8 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 {
     static_assert(NS >= 2 && NS % 2 == 0, "fuse an even number of colour passes");
     constexpr int RING = ring_rows(NS);
-    static_assert(RING % 6 == 0 && RING % kPrefetch == 0 && RING >= NS + 1, "ring geometry");
+    constexpr int kPrefetch = B::kPrefetch;
+    static_assert(RING % 6 == 0 && 6 % kPrefetch == 0 && RING >= NS + 1, "ring geometry");
     Pipe<B, NS> pp;
     bk.poison(pp);  // no-op on the GPU; NaN-fills in the emulator to prove nothing stale leaks
 
@@ -220,17 +230,23 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 }
 
 // ---- tiling arithmetic shared by the launcher, the kernel and the emulator -----------------
+// A wave tile is `tile_cols` columns wide (64 lanes x 2 or 4 cells); its outer `halo_cols`
+// columns on each side (NS rounded up to the lane's access granularity) are spoiled by the NS
+// passes, the rest is exact.  Strips are laid out so that strip 0's exact interior starts at
+// column 0.
 struct Tiling {
     int ns;          // passes fused
     int dim_x;
     int g_begin, g_end;   // output rows
     int rows_per_chunk;
     int n_strips, n_chunks;
+    int tile_cols, halo_cols;
 };
 
-SFL_HD int strip_step(int ns) { return kTileCols - 2 * ns; }  // output columns per strip
+SFL_HD int strip_step(const Tiling &t) { return t.tile_cols - 2 * t.halo_cols; }
 
-SFL_HD Tiling make_tiling(int ns, int dim_x, int g_begin, int g_end, int rows_per_chunk)
+SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g_begin, int g_end,
+                          int rows_per_chunk)
 {
     Tiling t;
     t.ns = ns;
@@ -238,13 +254,15 @@ SFL_HD Tiling make_tiling(int ns, int dim_x, int g_begin, int g_end, int rows_pe
     t.g_begin = g_begin;
     t.g_end = g_end;
     t.rows_per_chunk = rows_per_chunk;
-    t.n_strips = (dim_x + strip_step(ns) - 1) / strip_step(ns);
+    t.tile_cols = tile_cols;
+    t.halo_cols = (ns + col_align - 1) / col_align * col_align;
+    t.n_strips = (dim_x + strip_step(t) - 1) / strip_step(t);
     t.n_chunks = (g_end - g_begin + rows_per_chunk - 1) / rows_per_chunk;
     return t;
 }
 
-// column of lane 0's cell `a` for a strip (may be negative: columns left of the domain)
-SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t.ns) - t.ns; }
+// column of lane 0's first cell for a strip (may be negative: columns left of the domain)
+SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t) - t.halo_cols; }
 
 // does the tile (strip, chunk) touch the domain boundary (=> EDGE path)?
 SFL_HD bool tile_touches_boundary(const Tiling &t, int strip, int chunk, int gdim_y)
@@ -252,8 +270,8 @@ SFL_HD bool tile_touches_boundary(const Tiling &t, int strip, int chunk, int gdi
     const int x0 = strip_x0(t, strip);
     const int r0 = t.g_begin + chunk * t.rows_per_chunk;
     const int r1 = (r0 + t.rows_per_chunk < t.g_end) ? r0 + t.rows_per_chunk : t.g_end;
-    // rows entering the pipeline: [r0 - ns - 1, r1 + ns + ring); columns [x0, x0 + 128)
-    return x0 <= 0 || x0 + kTileCols >= t.dim_x || r0 - t.ns - 1 <= 0 ||
+    // rows entering the pipeline: [r0 - ns - 1, r1 + ns + ring); columns [x0, x0 + tile_cols)
+    return x0 <= 0 || x0 + t.tile_cols >= t.dim_x || r0 - t.ns - 1 <= 0 ||
            r1 + t.ns + ring_rows(t.ns) >= gdim_y;
 }
 

@@ -63,6 +63,8 @@ extern "C" {
 #define SFL_OPT_SOR_ROWS 3     /* output rows per wave chunk of kernel 2 (0 = auto)             */
 #define SFL_OPT_TRANSPORT 4    /* 0 = RCCL send/recv, 1 = in-process copies between the virtual
                                   ranks of a sfl_group (single device; test / bring-up)         */
+#define SFL_OPT_SOR_LANE_CELLS 5 /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
+                                  width), 4 = packed fp32 (dim_x % 4 == 0; else falls back to 2) */
 
 typedef struct sfl_context sfl_context;
 

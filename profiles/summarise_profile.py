@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (rocprofv3 CSVs) into a short text summary:
+per-kernel launch count / average duration from the kernel trace, and per-kernel average PMC
+values from each counter pass.  FETCH_SIZE / WRITE_SIZE are reported raw (KiB) and converted to
+bytes per launch with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE x2)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def short(name):
+    import re
+    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+), (?:(true|false), )?(true|false)>, \d+, (true|false), (true|false)>", name)
+    if m:
+        return (f"sor_fused_kernel<Lane{m.group(1)}, NS={m.group(2)}, dx1={m.group(5)}, "
+                f"zero_in={m.group(6)}>")
+    for key in ("sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
+                "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):
+        if key in name:
+            return key
+    return name[:70]
+
+
+print(f"# profile summary of {os.path.basename(root)}")
+for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True)):
+    dur = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        dur[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    print("\n## kernel trace (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
+    print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s}")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k:70s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f}")
+
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        acc = defaultdict(lambda: defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        print("\n## PMC pass:", os.path.relpath(f, root))
+        for k, cs in sorted(acc.items()):
+            for c, v in sorted(cs.items()):
+                avg = sum(v) / len(v)
+                extra = ""
+                if c == "FETCH_SIZE":
+                    extra = f"  -> {avg * 1024 * 2 / 1e6:.1f} MB/launch read (x2 gfx950 correction), raw {avg * 1024 / 1e6:.1f} MB"
+                if c == "WRITE_SIZE":
+                    extra = f"  -> {avg * 1024 / 1e6:.1f} MB/launch written (uncalibrated)"
+                print(f"{k:70s} {c:28s} n={len(v):4d} avg={avg:16.1f}{extra}")

@@ -43,6 +43,7 @@ EMU_BINOP(*)
 struct EmuBackend {
     using V = V64;
     using M = M64;
+    static constexpr int kPrefetch = 6;
 
     const float *p_in;
     const float *d;
@@ -167,7 +168,7 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
                bool vec2, bool poison, bool force_edge)
 {
     using namespace sfl::sor;
-    const Tiling t = make_tiling(NS, dim_x, g_begin, g_end, rows_per_chunk);
+    const Tiling t = make_tiling(NS, 128, 2, dim_x, g_begin, g_end, rows_per_chunk);
     for (int chunk = 0; chunk < t.n_chunks; ++chunk) {
         for (int strip = 0; strip < t.n_strips; ++strip) {
             EmuBackend bk;
@@ -180,8 +181,8 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
             bk.row_lo = grow0 > 0 ? grow0 : 0;
             bk.row_hi = (grow0 + lrows < gdim_y) ? grow0 + lrows : gdim_y;
             bk.x0 = strip_x0(t, strip);
-            bk.out_lo = bk.x0 + NS;
-            bk.out_hi = bk.x0 + kTileCols - NS;
+            bk.out_lo = bk.x0 + t.halo_cols;
+            bk.out_hi = bk.x0 + t.tile_cols - t.halo_cols;
             bk.vec2 = vec2;
             bk.poison_on = poison;
             bk.ring.assign((size_t)ring_rows(NS) * 2 * 64,

@@ -69,6 +69,24 @@ def test_sor_fused_vs_oracle(sfl, oracle, dim_x, dim_y):
                      oracle.poisson_solve(d, 0.5, 5, np.float32(1.3)), "dx 0.5 omega 1.3")
 
 
+LANE4_SHAPES = [(4, 4), (8, 3), (64, 48), (128, 64), (256, 40), (260, 70), (512, 96), (1024, 50), (1500, 33)]
+
+
+@pytest.mark.parametrize("dim_x,dim_y", LANE4_SHAPES)
+def test_sor_fused_packed_lane4_vs_oracle(sfl, oracle, dim_x, dim_y):
+    """4 cells per lane, packed fp32 (v_pk_add_f32 / v_pk_mul_f32): same bits as the scalar path."""
+    _, _, d = random_fields(dim_x, dim_y, 4)
+    for fuse, iters, rows in [(2, 1, 0), (4, 3, 16), (8, 4, 0), (8, 9, 24), (16, 8, 0), (6, 7, 0),
+                              (12, 6, 0), (14, 7, 20), (10, 5, 0)]:
+        hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_rows=rows, sor_lane_cells=4)
+        assert_bit_equal(hp.poisson_solve(d, 1.0, iters, OMEGA),
+                         oracle.poisson_solve(d, 1.0, iters, OMEGA),
+                         f"lane4 {dim_x}x{dim_y} fuse {fuse} iters {iters}")
+    hp = sfl.HostPath(sor_kernel=2, sor_fuse=8, sor_lane_cells=4)
+    assert_bit_equal(hp.poisson_solve(d, 0.5, 5, np.float32(1.3)),
+                     oracle.poisson_solve(d, 0.5, 5, np.float32(1.3)), "lane4 dx 0.5 omega 1.3")
+
+
 @pytest.mark.parametrize("dim_x,dim_y", SHAPES)
 def test_operators_vs_oracle(hip, oracle, dim_x, dim_y):
     for seed, vamp in [(1, 100.0), (2, 1000.0), (3, 0.0)]:
