@@ -63,23 +63,40 @@ def synthetic_color(dim_x, row_begin, row_end, seed=777):
     return ((h >> np.uint64(20)) & np.uint64(0x7FFFFFFF)).astype(np.uint32)   # raw < 2^31
 
 
-def cpu_baseline(size, budget_s=12.0):
-    """Reference CPU loop (1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(size, iters, budget_s=12.0):
+    """Reference CPU loop (1 thread) on a bounded sample of the same workload: whole
+    poisson_solve calls on the same grid, repeated until ~budget_s of CPU time is spent."""
     from oracle import loader  # checker / baseline only
     path = loader.reference() if loader.reference_available() else loader.port()
     d = np.random.default_rng(5).standard_normal((size, size)).astype(np.float32) * np.float32(0.1)
     t0 = time.perf_counter()
     path.poisson_solve(d, 1.0, 2, np.float32(1.96))
-    probe = (time.perf_counter() - t0) / 2
-    iters = int(max(2, min(80, budget_s / max(probe, 1e-6))))
+    per_iter = (time.perf_counter() - t0) / 2
+    run_iters = int(max(2, min(iters, budget_s / max(per_iter, 1e-9))))
+    reps = int(max(1, round(budget_s / max(per_iter * run_iters, 1e-9))))
     t0 = time.perf_counter()
-    path.poisson_solve(d, 1.0, iters, np.float32(1.96))
+    for _ in range(reps):
+        path.poisson_solve(d, 1.0, run_iters, np.float32(1.96))
     dt = time.perf_counter() - t0
-    return {"value": size * size * iters / dt, "unit": "cell-iters/s", "cores": 1,
+    return {"value": size * size * run_iters * reps / dt, "unit": "cell-iters/s", "cores": 1,
             "kind": path.kind,
-            "sample": f"poisson_solve {size}x{size} fp32, {iters} iters, 1 thread, {dt:.1f} s "
-                      f"({'unmodified reference sources' if path.kind == 'reference' else 'oracle C port'}, "
+            "sample": f"{reps} x poisson_solve {size}x{size} fp32, {run_iters} iters each, 1 thread, "
+                      f"{dt:.1f} s ({'unmodified reference sources' if path.kind == 'reference' else 'oracle C port'}, "
                       f"g++/gcc -O2 -ffp-contract=off)"}
+
+
+def pmc_traffic(size, fuse, lane_cells, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json), or None when no entry matches this exact configuration."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
+    except Exception:
+        return None
+    for e in table:
+        if (e["grid"] == [size, size] and e["fuse"] == fuse and e["lane_cells"] == lane_cells
+                and e["n_gpus"] == world):
+            return e
+    return None
 
 
 def main():
@@ -194,6 +211,8 @@ def main():
         bytes_per_launch = SOR_BYTES_PER_CELL_ITER * (cells / world) * iters / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9
         name, cus, mem = sfl.device_info(local_rank)
+        lane_cells = s.get_option(capi.OPT_SOR_LANE_CELLS) or 2
+        pmc = pmc_traffic(size, info["fuse"], lane_cells, world)
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,7 +226,9 @@ def main():
                        "halo_exchanges_per_solve": info["exchanges"],
                        "half_sweeps_fused_per_launch": info["fuse"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                         "traffic_source": pmc["source"] if pmc else None,
                          "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
                          "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
@@ -215,7 +236,7 @@ def main():
             "device": name,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(size)
+            out["cpu_baseline"] = cpu_baseline(size, iters)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
 
