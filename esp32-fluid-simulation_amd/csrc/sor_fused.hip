@@ -343,25 +343,45 @@ int resident_waves()
     return cached;
 }
 
-// Output rows per wave tile: every tile costs the same, so the launch takes
-// ceil(tiles / resident waves) rounds; pick the chunk count that fills whole rounds with the
-// fewest rows of warm-up overhead (each chunk re-streams 2 * NS extra rows).
-inline int auto_rows_per_chunk(int rows, int strips, int ns, int waves)
+inline int device_simds()
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        return 1024;
+    }
+    cached = cus * 4;
+    return cached;
+}
+
+// Output rows per wave tile.  Every tile costs about the same (rows streamed = rpc + 2 NS of
+// warm-up), a SIMD works through its tiles essentially one VALU stream at a time, so a launch
+// takes about ceil(tiles / SIMDs) * (rpc + 2 NS) row-steps -- provided each SIMD holds ~2+ waves
+// to cover DS / memory latency (measured on 8192 x {1024, 8192}, profiles/r01_rows_per_chunk.txt:
+// fewer than ~2 waves per SIMD costs 1.4x, 2..3 waves ~1.08x).  Pick the chunk count that
+// minimises that, never exceeding the resident-wave capacity by less than a full round.
+inline int auto_rows_per_chunk(int rows, int strips, int ns, int waves, int simds)
 {
     int best_rows = rows;
     double best_cost = 1e300;
-    const int max_chunks = (rows + 15) / 16;
+    const int max_chunks = (rows + 7) / 8;
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
         const int real_chunks = (rows + rpc - 1) / rpc;
         const long tiles = (long)real_chunks * strips;
-        const long rounds = (tiles + waves - 1) / waves;
-        const double cost = (double)rounds * (rpc + 2 * ns + 2);
+        const double per_simd = (double)tiles / simds;
+        const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
+        const long rounds = (tiles + waves - 1) / waves;          // residency rounds
+        const double penalty = per_simd >= 2.8 ? 1.0 : per_simd >= 1.9 ? 1.08 : 1.45;
+        double cost = (double)(serial > rounds ? serial : rounds) * (rpc + 2 * ns + 2) * penalty;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best_rows = rpc;
         }
-        if (tiles > 8L * waves) break;
+        if (tiles > 12L * simds) break;
     }
     return best_rows;
 }
@@ -374,7 +394,7 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     const int rpc = rows_per_chunk > 0
                         ? rows_per_chunk
                         : auto_rows_per_chunk(g_end - g_begin, t.n_strips, NS,
-                                              resident_waves<B, NS, DX1, ZERO_IN>());
+                                              resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
     t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g_begin, g_end, rpc);
     const int tiles = t.n_strips * t.n_chunks;
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;

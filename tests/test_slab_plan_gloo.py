@@ -1,0 +1,109 @@
+"""CPU suite, multi-process: the PRODUCT's slab program (sfl_plan_poisson through the C ABI: which
+halo to exchange when, how many rows, which launches) is executed by `world_size` gloo ranks --
+gloo send/recv standing in for RCCL, the oracle's row-restricted colour pass standing in for the
+kernels -- and must reproduce the whole-domain reference solve bit for bit.  Ghost rows start as
+NaN, so an exchange that is missing, too shallow or too late poisons the result."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bit_equal
+
+OMEGA = np.float32(1.96)
+GHOST = 32
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _exchange(dist, torch, rank, world, arr, grow0, g0, g1, rows):
+    """Matched neighbour exchange of `rows` owned rows per side into the adjacent ghost rows."""
+    ops, bufs = [], []
+    lo, hi = g0 - grow0, g1 - grow0
+    def send(block, peer):
+        t = torch.from_numpy(np.ascontiguousarray(block))
+        bufs.append(t)
+        ops.append(dist.P2POp(dist.isend, t, peer))
+    def recv(slc, peer):
+        t = torch.empty((rows, arr.shape[1]), dtype=torch.float32)
+        bufs.append((t, slc))
+        ops.append(dist.P2POp(dist.irecv, t, peer))
+    if rank > 0:
+        send(arr[lo:lo + rows], rank - 1)
+        recv(slice(lo - rows, lo), rank - 1)
+    if rank < world - 1:
+        send(arr[hi - rows:hi], rank + 1)
+        recv(slice(hi, hi + rows), rank + 1)
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for b in bufs:
+        if isinstance(b, tuple):
+            arr[b[1]] = b[0].numpy()
+
+
+def _worker(rank, world, port, dim_x, dim_y, iters, fuse, kernel, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle import loader
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        sfl = importlib.import_module("esp32-fluid-simulation_amd")
+        orc = loader.port()
+        cap = sfl.capi
+        g0, g1 = sfl.slab_rows(dim_y, world, rank)
+        grow0 = g0 - GHOST
+        d_full = np.random.default_rng(99).standard_normal((dim_y, dim_x)).astype(np.float32)
+        lrows = g1 - g0 + 2 * GHOST
+        d = np.full((lrows, dim_x), np.nan, np.float32)
+        d[GHOST:GHOST + g1 - g0] = d_full[g0:g1]
+        p = np.full((lrows, dim_x), np.nan, np.float32)
+        fields = {cap.FIELD_PRESSURE: p, cap.FIELD_DIVERGENCE: d}
+        dom_lo, dom_hi = max(grow0, 0) - grow0, min(grow0 + lrows, dim_y) - grow0
+        n_exchanges = 0
+        for st in sfl.plan_poisson(dim_y, world, rank, iters, fuse, kernel):
+            if st.kind == cap.STEP_EXCHANGE:
+                _exchange(dist, torch, rank, world, fields[st.field], grow0, g0, g1, st.rows)
+                n_exchanges += 1
+            elif st.kind == cap.STEP_ZERO:
+                p[dom_lo:dom_hi] = 0.0
+            elif st.kind == cap.STEP_SOR:
+                if st.from_zero:
+                    p[dom_lo:dom_hi] = 0.0
+                n = st.nsweeps
+                for j in range(1, n + 1):
+                    a = max(st.g_begin - (n - j), 0)
+                    b = min(st.g_end + (n - j), dim_y)
+                    orc.sor_half_sweep_rows(p, d, dim_y, (st.first_colour + j - 1) & 1, a - grow0,
+                                            b - grow0, grow0, 1.0, OMEGA)
+        np.save(os.path.join(outdir, f"p_{rank}.npy"), p[GHOST:GHOST + g1 - g0])
+        np.save(os.path.join(outdir, f"n_{rank}.npy"), np.array([n_exchanges]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kernel,fuse,iters", [(2, 2, 8, 10), (2, 2, 16, 9), (2, 1, 2, 3),
+                                                    (3, 2, 4, 7), (2, 2, 6, 1)])
+def test_slab_program_over_gloo(tmp_path, oracle, world, kernel, fuse, iters):
+    import torch.multiprocessing as mp
+    dim_x, dim_y = 37, 140
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dim_x, dim_y, iters, fuse, kernel, str(tmp_path)),
+             nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"p_{r}.npy") for r in range(world)], axis=0)
+    d_full = np.random.default_rng(99).standard_normal((dim_y, dim_x)).astype(np.float32)
+    assert_bit_equal(got, oracle.poisson_solve(d_full, 1.0, iters, OMEGA), f"{world} gloo ranks")
+    n = int(np.load(tmp_path / "n_0.npy")[0])
+    if kernel == 2:   # one rhs exchange (if any launch fuses > 1 pass) + one per launch after the first
+        launches = -(-2 * iters // fuse)
+        assert n == (launches - 1) + 1
+    else:
+        assert n == 2 * iters - 1
