@@ -12,6 +12,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_RCCL, ERR_NOMEM, ERR_STATE, ERR_HALO = 0, -1, -2, 
 FIELD_VELOCITY, FIELD_COLOR, FIELD_DIVERGENCE, FIELD_PRESSURE = 0, 1, 2, 3
 OPT_SOR_KERNEL, OPT_SOR_FUSE, OPT_ADVECT_HALO, OPT_SOR_ROWS, OPT_TRANSPORT = 0, 1, 2, 3, 4
 OPT_SOR_LANE_CELLS = 5
+OPT_SOR_HALO = 6
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
@@ -69,7 +70,7 @@ SIGNATURES = {
     "sfl_device_count": (_i, [_pi]),
     "sfl_device_info": (_i, [_i, C.c_char_p, _sz, _pi, C.POINTER(_sz)]),
     "sfl_slab_rows": (_i, [_i, _i, _i, _pi, _pi]),
-    "sfl_plan_poisson": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(PlanStep), _i, _pi]),
+    "sfl_plan_poisson": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(PlanStep), _i, _pi]),
     "sfl_sor_pass_plan": (_i, [_i, _i, _pi, _pi, _i]),
     "sfl_host_advect_vec2f": (_i, [_pf, _pf, _pf, _i, _i, _f, _i]),
     "sfl_host_advect_vec3uq32": (_i, [_pu, _pu, _pf, _i, _i, _f, _i]),

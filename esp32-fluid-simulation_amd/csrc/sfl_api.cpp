@@ -58,7 +58,7 @@ int fail(int code, const char *fmt, ...)
         if (rc_ != SFL_OK) return rc_; \
     } while (0)
 
-constexpr int kGhostRows = 32;  // ghost rows allocated per side on a slab (nranks > 1)
+constexpr int kGhostRows = 64;  // ghost rows allocated per side on a slab (nranks > 1)
 
 size_t field_elem_bytes(int field)
 {
@@ -101,7 +101,7 @@ struct sfl_context {
     int d_force_cap = 0;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_transport = 0, opt_sor_lane_cells = 0;
+        opt_transport = 0, opt_sor_lane_cells = 0, opt_sor_halo = 0;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -271,6 +271,14 @@ int effective_fuse(const sfl_context *c)
 
 int effective_kernel(const sfl_context *c) { return c->opt_sor_kernel == 1 ? 1 : 2; }
 
+int effective_halo(const sfl_context *c, int fuse)
+{
+    int h = c->opt_sor_halo ? c->opt_sor_halo : 32;
+    if (h > min_owned_rows(c)) h = min_owned_rows(c);  // a neighbour can only send rows it owns
+    if (h > kGhostRows) h = kGhostRows;
+    return h < fuse ? fuse : h;
+}
+
 // ---- poisson_solve executor --------------------------------------------------------------
 int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm)
 {
@@ -305,7 +313,8 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
-        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel));
+        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel,
+                                          effective_halo(ctx, fuse)));
         c->last_launches = c->last_exchanges = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
@@ -426,13 +435,14 @@ int sfl_sor_pass_plan(int iters, int fuse, int *n_passes, int *passes, int cap)
     return SFL_OK;
 }
 
-int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
+int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel, int halo,
                      sfl_plan_step *steps, int cap, int *n_steps)
 {
     if (dim_y < 2 || nranks < 1 || rank < 0 || rank >= nranks || iters < 0 || !n_steps ||
         (kernel != 1 && kernel != 2) || (kernel == 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
         return fail(SFL_ERR_INVALID, "bad plan query");
-    const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel);
+    if (halo < 0) return fail(SFL_ERR_INVALID, "bad plan query");
+    const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo);
     *n_steps = (int)v.size();
     if (steps)
         for (int k = 0; k < (int)v.size() && k < cap; ++k) steps[k] = v[k];
@@ -534,6 +544,11 @@ int sfl_set_option(sfl_context *c, int option, int value)
         case SFL_OPT_TRANSPORT:
             c->opt_transport = value;
             return SFL_OK;
+        case SFL_OPT_SOR_HALO:
+            if (value != 0 && (value < 2 || value > kGhostRows))
+                return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
+            c->opt_sor_halo = value;
+            return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS:
             if (value != 0 && value != 2 && value != 4)
                 return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto), 2 or 4");
@@ -553,6 +568,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
         case SFL_OPT_TRANSPORT: *value = c->opt_transport; return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
+        case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }

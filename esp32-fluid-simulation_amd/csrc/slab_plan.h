@@ -23,7 +23,8 @@ std::vector<int> sor_pass_plan(int iters, int fuse);
 
 // Program of one poisson_solve for one rank; every rank's program has the same length and the
 // same kinds at the same positions (exchanges are matched pairs).
+// halo = rows of p exchanged per superstep (>= fuse; kernel 2 only)
 std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse,
-                                        int kernel);
+                                        int kernel, int halo);
 
 }  // namespace sfl

@@ -53,13 +53,15 @@ def sor_pass_plan(iters: int, fuse: int):
     return list(arr[: n.value])
 
 
-def plan_poisson(dim_y: int, nranks: int, rank: int, iters: int, fuse: int = 8, kernel: int = 2):
-    """The launch / halo-exchange program of one poisson_solve for one rank (pure arithmetic)."""
+def plan_poisson(dim_y: int, nranks: int, rank: int, iters: int, fuse: int = 8, kernel: int = 2,
+                 halo: int = 0):
+    """The launch / halo-exchange program of one poisson_solve for one rank (pure arithmetic).
+    halo = rows of p exchanged per superstep (0: exchange before every launch)."""
     n = C.c_int()
-    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, None, 0,
+    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, None, 0,
                                            C.byref(n)))
     steps = (capi.PlanStep * max(n.value, 1))()
-    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, steps,
+    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, steps,
                                            n.value, C.byref(n)))
     return [steps[k] for k in range(n.value)]
 

@@ -64,6 +64,9 @@ extern "C" {
 #define SFL_OPT_SOR_ROWS 3     /* output rows per wave chunk of kernel 2 (0 = auto)             */
 #define SFL_OPT_TRANSPORT 4    /* 0 = RCCL send/recv, 1 = in-process copies between the virtual
                                   ranks of a sfl_group (single device; test / bring-up)         */
+#define SFL_OPT_SOR_HALO 6     /* rows of p exchanged per superstep on a slab (kernel 2): 0 = auto
+                                  (32), else fuse..64; larger = fewer, larger exchanges and more
+                                  redundantly recomputed ghost rows                             */
 #define SFL_OPT_SOR_LANE_CELLS 5 /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
                                   width), 4 = packed fp32 (dim_x % 4 == 0; else falls back to 2) */
 
@@ -92,7 +95,7 @@ typedef struct sfl_plan_step {
     int32_t field;        /* EXCHANGE: SFL_FIELD_* whose halo rows are refreshed              */
     int32_t rows;         /* EXCHANGE: rows per side (sent from / received next to the owned
                              block); 0 on compute steps                                       */
-    int32_t g_begin;      /* compute: first output row                                        */
+    int32_t g_begin;      /* compute: first output row (may extend into the ghost rows)       */
     int32_t g_end;        /* compute: one past the last output row                            */
     int32_t nsweeps;      /* SOR: colour passes executed by this launch.  Pass j (1-based)
                              covers rows [g_begin-(nsweeps-j), g_end+(nsweeps-j)) clipped to
@@ -108,11 +111,14 @@ typedef struct sfl_plan_step {
 
 /* Program of one poisson_solve on slab `rank` of `nranks`: kernel = 1 (one colour pass per
  * launch, 1-row exchange before every pass but the first) or 2 (fused: `fuse` passes per
- * launch, `fuse`-row exchange before every launch but the first, plus one exchange of the
- * right-hand side up front).  Writes at most `cap` steps, returns the total in *n_steps.
- * Pure arithmetic, no GPU needed; the GPU executor walks exactly this program.                */
+ * launch; launches are grouped into supersteps of at most `halo` passes in total, with ONE
+ * exchange of that many rows of p before every superstep but the first -- ghost rows are
+ * recomputed redundantly in between -- plus one exchange of the right-hand side up front).
+ * halo is clamped to >= fuse; halo == fuse exchanges before every launch.  Writes at most `cap`
+ * steps, returns the total in *n_steps.  Pure arithmetic, no GPU needed; the GPU executor
+ * walks exactly this program.                                                                */
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
-                             sfl_plan_step *steps, int cap, int *n_steps);
+                             int halo, sfl_plan_step *steps, int cap, int *n_steps);
 
 /* Pass plan of one poisson_solve: 2*iters half-sweeps are executed as `*n_passes` launches of
  * at most `fuse` half-sweeps each (the last one may be shorter); passes[k] receives the

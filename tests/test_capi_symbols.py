@@ -66,6 +66,23 @@ def test_poisson_program_shape(sfl):
     for r in range(8):  # same skeleton on every rank, own rows as output
         assert [s.kind for s in progs[r]] == kinds
         assert all((s.g_begin, s.g_end) == sfl.slab_rows(8192, 8, r) for s in progs[r] if s.kind == S)
+    # supersteps: halo 32 at fuse 8 -> 5 groups of 4 launches, 4 exchanges of 32 rows, rhs 31 rows;
+    # inside a group the output range shrinks by 8 rows per launch down to the owned rows
+    prog = sfl.plan_poisson(8192, 8, 3, 80, 8, 2, 32)
+    assert [s.kind for s in prog] == [E] + [S] * 4 + ([E] + [S] * 4) * 4
+    assert prog[0].field == sfl.capi.FIELD_DIVERGENCE and prog[0].rows == 31
+    assert all(s.rows == 32 for s in prog[1:] if s.kind == E)
+    g0, g1 = sfl.slab_rows(8192, 8, 3)
+    assert [(s.g_begin, s.g_end) for s in prog[1:5]] == [(g0 - 24, g1 + 24), (g0 - 16, g1 + 16),
+                                                         (g0 - 8, g1 + 8), (g0, g1)]
+    assert [s.from_zero for s in prog if s.kind == S] == [1] + [0] * 19
+    # the domain's bottom / top slabs never reach outside the domain
+    lo, hi = sfl.plan_poisson(8192, 8, 0, 80, 8, 2, 32), sfl.plan_poisson(8192, 8, 7, 80, 8, 2, 32)
+    assert min(s.g_begin for s in lo if s.kind == S) == 0
+    assert max(s.g_end for s in hi if s.kind == S) == 8192
+    # a short last superstep exchanges only what it needs: 10 iters at fuse 8 = launches 8, 8, 4
+    prog = sfl.plan_poisson(400, 2, 0, 10, 8, 2, 16)
+    assert [(s.kind, s.rows or s.nsweeps) for s in prog] == [(E, 15), (S, 8), (S, 8), (E, 4), (S, 4)]
     # baseline: zero fill, then exchange before every colour pass but the first
     prog = sfl.plan_poisson(100, 2, 1, 2, 8, 1)
     assert [s.kind for s in prog] == [Z, S, E, S, E, S, E, S]

@@ -145,8 +145,9 @@ def test_forces_are_injected_between_advect_and_divergence(sfl, oracle):
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 4])
-@pytest.mark.parametrize("kernel,fuse", [(1, 2), (2, 4), (2, 8)])
-def test_virtual_slabs_match_single_context(sfl, oracle, nranks, kernel, fuse):
+@pytest.mark.parametrize("kernel,fuse,halo", [(1, 2, 0), (2, 4, 4), (2, 8, 0), (2, 8, 32), (2, 16, 32),
+                                              (2, 6, 20)])
+def test_virtual_slabs_match_single_context(sfl, oracle, nranks, kernel, fuse, halo):
     """Row-slab decomposition on ONE device (in-process halo copies instead of RCCL): the slab
     executor, halo bookkeeping and slab-aware kernels must reproduce the whole-domain result
     bit for bit."""
@@ -159,6 +160,7 @@ def test_virtual_slabs_match_single_context(sfl, oracle, nranks, kernel, fuse):
         for s in slabs:
             s.set_option(sfl.capi.OPT_SOR_KERNEL, kernel)
             s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            s.set_option(sfl.capi.OPT_SOR_HALO, halo)
             s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
             s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
         slabs[0].step(DT, 1.0, iters, OMEGA)     # collective over the linked group

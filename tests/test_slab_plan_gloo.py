@@ -14,7 +14,7 @@ import pytest
 from conftest import ROOT, assert_bit_equal
 
 OMEGA = np.float32(1.96)
-GHOST = 32
+GHOST = 64
 
 
 def _free_port():
@@ -48,7 +48,7 @@ def _exchange(dist, torch, rank, world, arr, grow0, g0, g1, rows):
             arr[b[1]] = b[0].numpy()
 
 
-def _worker(rank, world, port, dim_x, dim_y, iters, fuse, kernel, outdir):
+def _worker(rank, world, port, dim_x, dim_y, iters, fuse, kernel, halo, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -69,7 +69,7 @@ def _worker(rank, world, port, dim_x, dim_y, iters, fuse, kernel, outdir):
         fields = {cap.FIELD_PRESSURE: p, cap.FIELD_DIVERGENCE: d}
         dom_lo, dom_hi = max(grow0, 0) - grow0, min(grow0 + lrows, dim_y) - grow0
         n_exchanges = 0
-        for st in sfl.plan_poisson(dim_y, world, rank, iters, fuse, kernel):
+        for st in sfl.plan_poisson(dim_y, world, rank, iters, fuse, kernel, halo):
             if st.kind == cap.STEP_EXCHANGE:
                 _exchange(dist, torch, rank, world, fields[st.field], grow0, g0, g1, st.rows)
                 n_exchanges += 1
@@ -90,20 +90,21 @@ def _worker(rank, world, port, dim_x, dim_y, iters, fuse, kernel, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kernel,fuse,iters", [(2, 2, 8, 10), (2, 2, 16, 9), (2, 1, 2, 3),
-                                                    (3, 2, 4, 7), (2, 2, 6, 1)])
-def test_slab_program_over_gloo(tmp_path, oracle, world, kernel, fuse, iters):
+@pytest.mark.parametrize("world,kernel,fuse,iters,halo", [(2, 2, 8, 10, 0), (2, 2, 16, 9, 32), (2, 1, 2, 3, 0),
+                                                         (3, 2, 4, 7, 16), (2, 2, 8, 13, 32)])
+def test_slab_program_over_gloo(tmp_path, oracle, world, kernel, fuse, iters, halo):
     import torch.multiprocessing as mp
     dim_x, dim_y = 37, 140
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, dim_x, dim_y, iters, fuse, kernel, str(tmp_path)),
+    mp.spawn(_worker, args=(world, port, dim_x, dim_y, iters, fuse, kernel, halo, str(tmp_path)),
              nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"p_{r}.npy") for r in range(world)], axis=0)
     d_full = np.random.default_rng(99).standard_normal((dim_y, dim_x)).astype(np.float32)
     assert_bit_equal(got, oracle.poisson_solve(d_full, 1.0, iters, OMEGA), f"{world} gloo ranks")
     n = int(np.load(tmp_path / "n_0.npy")[0])
-    if kernel == 2:   # one rhs exchange (if any launch fuses > 1 pass) + one per launch after the first
+    if kernel == 2:   # one rhs exchange + one per superstep after the first
         launches = -(-2 * iters // fuse)
-        assert n == (launches - 1) + 1
+        per_group = max(halo, fuse) // fuse
+        assert n == (-(-launches // per_group) - 1) + 1
     else:
         assert n == 2 * iters - 1
