@@ -118,6 +118,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if "SFL_BENCH_DEVICE" in os.environ:   # bring-up aid: several ranks on one device
+        local_rank = int(os.environ["SFL_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE={world})")

@@ -604,6 +604,22 @@ int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
     return SFL_OK;
 }
 
+int sfl_comm_loopback(sfl_context *c, int rows)
+{
+    if (!c || rows < 1 || rows > c->g1 - c->g0) return fail(SFL_ERR_INVALID, "bad loopback request");
+    if (!c->comm) return fail(SFL_ERR_STATE, "no communicator attached");
+    SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+    SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+    SFL_TRY(use_device(c));
+    const size_t bytes = (size_t)rows * c->dim_x * 4;
+    const size_t off = c->owned_offset_cells();
+    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(ncclSend(c->div + off, bytes, ncclChar, c->rank, c->comm, c->stream));
+    NCCL_TRY(ncclRecv(c->p + off, bytes, ncclChar, c->rank, c->comm, c->stream));
+    NCCL_TRY(ncclGroupEnd());
+    return SFL_OK;
+}
+
 int sfl_group_link(sfl_context **ctxs, int n)
 {
     if (!ctxs || n < 1) return fail(SFL_ERR_INVALID, "bad group");

@@ -116,6 +116,9 @@ class Solver:
     def comm_attach(self, unique_id: bytes):
         capi.check(self._lib.sfl_comm_attach(self._h, unique_id, len(unique_id)))
 
+    def comm_loopback(self, rows: int):
+        capi.check(self._lib.sfl_comm_loopback(self._h, rows))
+
     @staticmethod
     def link_group(solvers):
         """Join slabs living on one device into an in-process group (virtual ranks)."""

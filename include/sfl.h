@@ -174,6 +174,11 @@ SFL_API int sfl_slab_of(sfl_context *ctx, int *row_begin, int *row_end, int *ran
  *     torch.distributed broadcast), every rank attaches.  id_bytes = 128.                  */
 SFL_API int sfl_comm_unique_id(void *id_out, size_t id_bytes);
 SFL_API int sfl_comm_attach(sfl_context *ctx, const void *id, size_t id_bytes);
+/* RCCL bring-up check for boxes with a single GPU (a communicator cannot hold two ranks of one
+ * device): inside one ncclGroup, send the first `rows` owned rows of the divergence field to
+ * this rank itself and receive them into the first `rows` owned rows of the pressure field --
+ * the same pointer / count / stream arithmetic as a neighbour halo exchange.                  */
+SFL_API int sfl_comm_loopback(sfl_context *ctx, int rows);
 /* In-process transport between virtual ranks living on ONE device (bring-up / tests):
  * ctxs[r] must be slab r of nranks == n, all created on the same device.                   */
 SFL_API int sfl_group_link(sfl_context **ctxs, int n);

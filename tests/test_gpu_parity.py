@@ -205,3 +205,10 @@ def test_rccl_single_rank_communicator(sfl, oracle):
         s.synchronize()
         assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, 6, OMEGA),
                          "rccl 1-rank")
+        # real ncclSend / ncclRecv on the solver's stream (to itself: one GPU cannot host 2 ranks)
+        s.upload(sfl.capi.FIELD_PRESSURE, np.zeros_like(d))
+        s.comm_loopback(17)
+        s.synchronize()
+        got = s.download(sfl.capi.FIELD_PRESSURE)
+        assert_bit_equal(got[:17], d[:17], "loopback rows")
+        assert not got[17:].any()
