@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -155,7 +156,16 @@ def main():
     if world > 1:
         uid = [sfl.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        s.comm_attach(uid[0])
+        # RCCL prints a version banner on stdout while the communicator comes up; keep stdout
+        # clean for the ONE JSON line by pointing fd 1 at stderr for the duration of the call
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            s.comm_attach(uid[0])
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # synthetic inputs, resident in HBM before anything is timed
     s.upload(capi.FIELD_VELOCITY, synthetic_velocity(size, s.row_begin, s.row_end))
@@ -244,6 +254,7 @@ def main():
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out), flush=True)
 
+    barrier()
     s.close()
     if world > 1:
         dist.barrier()

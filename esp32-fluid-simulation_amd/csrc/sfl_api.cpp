@@ -273,7 +273,9 @@ int effective_kernel(const sfl_context *c) { return c->opt_sor_kernel == 1 ? 1 :
 
 int effective_halo(const sfl_context *c, int fuse)
 {
-    int h = c->opt_sor_halo ? c->opt_sor_halo : 32;
+    // auto: 64 rows on slabs of >= 1024 rows (2-3 exchanges per 80-iteration solve, ~5 % extra
+    // rows recomputed), 32 on thinner ones
+    int h = c->opt_sor_halo ? c->opt_sor_halo : (min_owned_rows(c) >= 1024 ? 64 : 32);
     if (h > min_owned_rows(c)) h = min_owned_rows(c);  // a neighbour can only send rows it owns
     if (h > kGhostRows) h = kGhostRows;
     return h < fuse ? fuse : h;

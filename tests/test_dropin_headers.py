@@ -102,3 +102,21 @@ def test_reference_style_caller_runs_on_gpu(tmp_path, oracle, dim_x, dim_y, iter
         v, d, p, c = oracle.step(v, c, dt, 1.0, iters, omega)
     for name, a, b in (("v", got_v, v), ("div", got_d, d), ("p", got_p, p), ("colour", got_c, c)):
         assert_bit_equal(a, b, f"drop-in caller: {name}")
+
+
+@pytest.mark.gpu
+def test_domain_for_each_runs_user_expressions_on_the_device(tmp_path, oracle):
+    """SURVEY 8f N4: user safe/fast functors through sfl/operations.h::domain_for_each."""
+    exe = tmp_path / "dfe"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17",
+                    "-ffp-contract=off", "-I", INC, os.path.join(CPP, "domain_for_each_test.hip"),
+                    "-o", str(exe)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dim_x, dim_y = 97, 45
+    v = (np.random.default_rng(1).uniform(-1, 1, (dim_y, dim_x, 2)) * 30).astype(np.float32)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("2i", dim_x, dim_y))
+        f.write(v.tobytes())
+    subprocess.run([str(exe), str(fin), str(fout)], check=True)
+    got = np.fromfile(fout, np.float32).reshape(dim_y, dim_x)
+    assert_bit_equal(got, oracle.divergence(v, 1.0), "domain_for_each divergence")

@@ -212,3 +212,43 @@ def test_rccl_single_rank_communicator(sfl, oracle):
         got = s.download(sfl.capi.FIELD_PRESSURE)
         assert_bit_equal(got[:17], d[:17], "loopback rows")
         assert not got[17:].any()
+
+
+def test_headline_size_spot_check_vs_oracle(sfl, oracle):
+    """8192 x 8192 (BASELINE config 3 grid), 4 iterations: the HIP path against the oracle on the
+    full-size grid, every cell, both lane flavours (SURVEY 8d parity gate)."""
+    n = 8192
+    rng = np.random.default_rng(2026)
+    d = (rng.standard_normal((n, n)) * 0.05).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, 4, OMEGA)
+    for lane, fuse in ((2, 8), (4, 4), (2, 16)):
+        hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_lane_cells=lane)
+        assert_bit_equal(hp.poisson_solve(d, 1.0, 4, OMEGA), want, f"8192^2 lane{lane} fuse{fuse}")
+
+
+def test_large_grid_properties(sfl):
+    """16384 x 16384 (BASELINE config 5 grid): size-independent properties instead of an oracle
+    run -- (1) the fused kernel (any fuse depth, either lane flavour) and the one-launch-per-pass
+    baseline kernel are different programs that must agree bit for bit; (2) a zero right-hand
+    side keeps the pressure at (signed) zero; (3) the solve is deterministic."""
+    n, iters = 16384, 3
+    with sfl.Solver(n, n) as s:
+        rng = np.random.default_rng(7)
+        d = (rng.standard_normal((n, n)) * 0.1).astype(np.float32)
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        results = []
+        for kernel, fuse, lane in ((1, 0, 0), (2, 6, 2), (2, 16, 2), (2, 4, 4), (2, 6, 2)):
+            s.set_option(sfl.capi.OPT_SOR_KERNEL, kernel)
+            if fuse:
+                s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            s.set_option(sfl.capi.OPT_SOR_LANE_CELLS, lane)
+            s.poisson_solve(1.0, iters, OMEGA)
+            s.synchronize()
+            results.append(s.download(sfl.capi.FIELD_PRESSURE))
+        for k, r in enumerate(results[1:], 1):
+            assert_bit_equal(r, results[0], f"16384^2 variant {k} vs baseline kernel")
+        assert np.isfinite(results[0]).all() and np.abs(results[0]).max() > 0
+        s.upload(sfl.capi.FIELD_DIVERGENCE, np.zeros((n, n), np.float32))
+        s.poisson_solve(1.0, iters, OMEGA)
+        s.synchronize()
+        assert not np.abs(s.download(sfl.capi.FIELD_PRESSURE)).any()
