@@ -197,24 +197,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
-    # full sim step, timed separately (not part of `value`)
-    sim_sps = None
+    # full sim step, timed separately (not part of `value`).  A slab reports a back-trace that
+    # left its advection halo at synchronize(); every rank still issues the same launches and
+    # exchanges, so the failure is recorded, agreed on collectively and never deadlocks a barrier.
+    sim_sps, sim_note = None, None
     if args.sim_steps > 0:
+        failed = []
+
+        def sync_soft():
+            try:
+                s.synchronize()
+            except sfl.SflError as e:
+                failed.append(str(e))
+
+        if world > 1:   # generous advection halo: the projected velocity is not bounded by vamp
+            s.set_option(capi.OPT_ADVECT_HALO, 32)
         dtf = np.float32(1 / 30.0)
         s.step(dtf, 1.0, iters, omega)
-        sync_all()
+        sync_soft()
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.sim_steps):
             s.step(dtf, 1.0, iters, omega)
-        sync_all()
+        sync_soft()
         barrier()
         sim_t = time.perf_counter() - t1
+        bad = 1.0 if failed else 0.0
         if world > 1:
-            t = torch.tensor([sim_t], dtype=torch.float64)
+            t = torch.tensor([sim_t, bad], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sim_t = float(t[0])
-        sim_sps = args.sim_steps / sim_t
+            sim_t, bad = float(t[0]), float(t[1])
+        if bad:
+            sim_note = failed[0] if failed else "a peer rank reported an advection-halo overflow"
+        else:
+            sim_sps = args.sim_steps / sim_t
 
     if rank == 0:
         cells = size * dim_y
@@ -247,6 +263,7 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "sim_steps_per_sec": sim_sps,
+            **({"sim_steps_note": sim_note} if sim_note else {}),
             "device": name,
         }
         if world == 1 and not args.no_cpu_baseline:
