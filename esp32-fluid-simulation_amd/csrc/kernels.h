@@ -39,6 +39,15 @@ hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, 
 hipError_t launch_subtract_gradient(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
                                     int g_end, float two_dx_inv);
 
+// Row-streaming variants (stream_stencils.hip): dim_x even, 16-byte aligned arrays.  The two
+// launchers above pick them automatically when applicable (SFL_STENCIL_BASELINE=1 in the
+// environment forces the one-thread-per-cell kernels, for A/B measurements).
+bool stream_stencils_applicable(const Slab &g, const void *a, const void *b);
+hipError_t launch_divergence_stream(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
+                                    int g_end, float two_dx_inv);
+hipError_t launch_gradient_stream(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
+                                  int g_end, float two_dx_inv);
+
 // ---- red-black SOR (poisson.cpp:14-112) ------------------------------------------------
 struct SorParams {
     float dx;

@@ -18,7 +18,7 @@ def short(name):
     if m:
         return (f"sor_fused_kernel<Lane{m.group(1)}, NS={m.group(2)}, dx1={m.group(5)}, "
                 f"zero_in={m.group(6)}>")
-    for key in ("sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
+    for key in ("divergence_stream_kernel", "gradient_stream_kernel", "sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
                 "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):
         if key in name:
             return key
