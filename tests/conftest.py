@@ -21,6 +21,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real AMD GPU (MI355X)")
 
 
+def _ensure_built():
+    """Build whatever is missing (fresh clone): the product library (hipcc cross-compiles gfx950
+    without a GPU), the C++ host layer, the oracle and the wave emulator.  No-ops when present."""
+    import subprocess
+    pkg = os.path.join(ROOT, "esp32-fluid-simulation_amd")
+    jobs = [
+        (os.path.join(pkg, "lib", "libsfl_hip.so"), ["make", "-C", os.path.join(pkg, "csrc"), "-j4"]),
+        (os.path.join(pkg, "lib", "libsfl_dropin.so"), ["make", "-C", os.path.join(pkg, "host")]),
+        (os.path.join(ROOT, "oracle", "libsf_oracle.so"), ["make", "-C", os.path.join(ROOT, "oracle")]),
+        (os.path.join(ROOT, "tests", "cpp", "libsor_stream_emu.so"), ["make", "-C", os.path.join(ROOT, "tests", "cpp")]),
+    ]
+    for artefact, cmd in jobs:
+        if not os.path.exists(artefact):
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+
+
+_ensure_built()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The C restatement of the reference CPU path (checker only)."""
