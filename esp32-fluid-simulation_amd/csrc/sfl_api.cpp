@@ -813,6 +813,26 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
     return SFL_OK;
 }
 
+int sfl_render_rgb565(sfl_context *c, int scaling, int byteswap, uint16_t *host_image, size_t bytes)
+{
+    if (!c || !host_image) return fail(SFL_ERR_INVALID, "NULL argument");
+    if (scaling < 1 || scaling > 64) return fail(SFL_ERR_INVALID, "scaling must be 1..64 (got %d)", scaling);
+    if (c->nranks != 1) return fail(SFL_ERR_STATE, "render needs a whole-domain context (slab %d/%d)", c->rank, c->nranks);
+    const size_t w = (size_t)scaling * (c->gdim_y - 1), h = (size_t)scaling * (c->dim_x - 1);
+    if (bytes != w * h * 2) return fail(SFL_ERR_INVALID, "image is %zu x %zu uint16 = %zu bytes, got %zu", h, w, w * h * 2, bytes);
+    SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+    SFL_TRY(use_device(c));
+    void *img = nullptr;
+    HIP_TRY(hipMalloc(&img, bytes));
+    hipError_t e = sfl::launch_render_rgb565(c->stream, static_cast<uint16_t *>(img), c->col, c->dim_x,
+                                             c->gdim_y, scaling, byteswap != 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_image, img, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(img);
+    if (e != hipSuccess) return fail(SFL_ERR_HIP, "render failed: %s", hipGetErrorString(e));
+    return SFL_OK;
+}
+
 int sfl_synchronize(sfl_context *ctx)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");

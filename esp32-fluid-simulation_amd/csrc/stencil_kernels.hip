@@ -270,6 +270,45 @@ sor_half_sweep_kernel(float *p, const float *__restrict__ d, Slab g, int g_begin
     p[c] = prm.one_minus_omega * p[c] + prm.omega * p_gs;  // :98, :111
 }
 
+// ---- dye visualiser (draw task, ino:116-176) ---------------------------------
+// One thread per output pixel.  Pixel (sy, sx) belongs to cell block (i, j) = (sy / S, sx / S)
+// at offset (ii, jj); it replays the sketch's strength-reduced lerps for its own offsets only:
+// left / right edge values after ii increments (:134-153), then jj increments across (:156-161),
+// narrowing to UQ32 (:168), RGB565 pack (:170-172), optional byte swap (:173).
+__global__ void __launch_bounds__(kBlock)
+render_rgb565_kernel(uint16_t *__restrict__ image, const uint32_t *__restrict__ colour, int dim_x,
+                     int dim_y, int scaling, int byteswap)
+{
+    const int width = scaling * (dim_y - 1);
+    const int sx = blockIdx.x * kBlock + threadIdx.x;
+    const int sy = blockIdx.y;
+    if (sx >= width) return;
+    const int i = sy / scaling, ii = sy - i * scaling;
+    const int j = sx / scaling, jj = sx - j * scaling;
+    const float inv = 1.0f / (float)scaling;
+    const uint32_t *t1 = colour + 3 * ((size_t)dim_x * j + i);
+    const uint32_t *t2 = colour + 3 * ((size_t)dim_x * (j + 1) + i);
+    uint32_t raw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float l = uq_widen(t1[k]), r = uq_widen(t2[k]);
+        const float dl = (uq_widen(t1[3 + k]) - l) * inv;
+        const float dr = (uq_widen(t2[3 + k]) - r) * inv;
+        for (int n = 0; n < ii; ++n) {
+            l += dl;
+            r += dr;
+        }
+        float c = l;
+        const float dc = (r - l) * inv;
+        for (int n = 0; n < jj; ++n) c += dc;
+        raw[k] = uq_narrow(c);
+    }
+    uint16_t px = (uint16_t)(((raw[0] & 0xF8000000u) >> 16) | ((raw[1] & 0xFC000000u) >> 21) |
+                             ((raw[2] & 0xF8000000u) >> 27));
+    if (byteswap) px = (uint16_t)((px >> 8) | (px << 8));
+    image[(size_t)sy * width + sx] = px;
+}
+
 __global__ void __launch_bounds__(kBlock)
 zero_rows_kernel(float *f, size_t first, size_t count)
 {
@@ -375,6 +414,16 @@ hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_
     const size_t want = (count + kBlock - 1) / kBlock;
     const int blocks = (int)(want < 4096 ? want : 4096);
     zero_rows_kernel<<<blocks, kBlock, 0, s>>>(f, first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_rgb565(hipStream_t s, uint16_t *image, const uint32_t *colour, int dim_x,
+                                int dim_y, int scaling, bool byteswap)
+{
+    const int width = scaling * (dim_y - 1), height = scaling * (dim_x - 1);
+    if (width <= 0 || height <= 0) return hipSuccess;
+    render_rgb565_kernel<<<dim3((width + kBlock - 1) / kBlock, height), kBlock, 0, s>>>(
+        image, colour, dim_x, dim_y, scaling, byteswap ? 1 : 0);
     return hipGetLastError();
 }
 

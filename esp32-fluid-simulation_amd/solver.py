@@ -174,6 +174,13 @@ class Solver:
             self._h, cells.ctypes.data_as(C.POINTER(C.c_int)),
             vel.ctypes.data_as(C.POINTER(C.c_float)), len(cells)))
 
+    def render_rgb565(self, scaling: int = 4, byteswap: bool = True) -> np.ndarray:
+        """Dye field -> RGB565 image, uint16[scaling*(dim_x-1), scaling*(dim_y-1)] (ino:116-176)."""
+        img = np.empty((scaling * (self.dim_x - 1), scaling * (self.dim_y - 1)), np.uint16)
+        capi.check(self._lib.sfl_render_rgb565(self._h, scaling, int(byteswap),
+                                               img.ctypes.data_as(C.POINTER(C.c_uint16)), img.nbytes))
+        return img
+
     def synchronize(self):
         capi.check(self._lib.sfl_synchronize(self._h))
 

@@ -212,6 +212,14 @@ SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omeg
  * in SIMULATION coordinates (the sketch's x/y swap is the caller's business).               */
 SFL_API int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n);
 
+/* --- dye visualiser (the arithmetic of the sketch's draw task, ino:116-176): every cell block
+ *     is up-scaled `scaling` x `scaling` by the sketch's incremental lerps, narrowed to UQ32 and
+ *     packed to RGB565 (byte-swapped like ino:173 when byteswap != 0).  `host_image` receives
+ *     scaling*(dim_x-1) rows of scaling*(dim_y-1) uint16 pixels: the sim's i axis runs down the
+ *     screen, j across (ino:164,180).  Whole-domain contexts only; synchronous.               */
+SFL_API int sfl_render_rgb565(sfl_context *ctx, int scaling, int byteswap, uint16_t *host_image,
+                              size_t bytes);
+
 /* --- synchronisation / timing on the context's stream ---------------------------------- */
 SFL_API int sfl_synchronize(sfl_context *ctx);
 /* HIP-event stopwatch on the compute stream: start, run work, stop -> elapsed ms (blocks

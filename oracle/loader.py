@@ -127,6 +127,9 @@ class OraclePort(CpuPath):
         self._lcg = lib.orc_lcg_fields
         self._lcg.argtypes = [_F, _U, C.c_int, C.c_int, C.c_uint32, C.c_float]
         self._lcg.restype = None
+        self._render = lib.orc_render_rgb565
+        self._render.argtypes = [C.POINTER(C.c_uint16), _U, C.c_int, C.c_int, C.c_int, C.c_int]
+        self._render.restype = None
         self._fnv = lib.orc_fnv1a64
         self._fnv.argtypes = [C.c_void_p, C.c_size_t]
         self._fnv.restype = C.c_uint64
@@ -142,6 +145,14 @@ class OraclePort(CpuPath):
         p = p.copy()
         self._iter(_fp(p), _fp(div), dim_x, dim_y, dx, iters, omega)
         return p
+
+    def render_rgb565(self, colour, scaling=4, byteswap=True):
+        """Draw-task arithmetic (ino:116-176; unpinned).  Returns uint16[scaling*(dim_x-1), scaling*(dim_y-1)]."""
+        dim_x, dim_y = self._dims(colour)
+        img = np.empty((scaling * (dim_x - 1), scaling * (dim_y - 1)), np.uint16)
+        self._render(img.ctypes.data_as(C.POINTER(C.c_uint16)), _up(colour), dim_x, dim_y, scaling,
+                     int(byteswap))
+        return img
 
     def lcg_fields(self, dim_x, dim_y, seed, vamp):
         v = np.empty((dim_y, dim_x, 2), np.float32)

@@ -19,6 +19,8 @@
  *                                            to a row range (used by the slab-sharding tests)
  *   orc_step                                 call order of ESP32-fluid-simulation.ino:252-287
  *                                            (no force injection, no RTOS hand-off)
+ *   orc_render_rgb565                        draw-task arithmetic, ino:116-176 (PARITY UNPINNED:
+ *                                            the .ino does not compile outside the Arduino core)
  *
  * Parity status: PINNED.  Every function is compared bit-for-bit against the
  * unmodified reference sources compiled in place (oracle/Makefile -> oracle/_ref,
@@ -348,6 +350,55 @@ ORC_API int orc_step(float *v, uint32_t *colour, float *div, float *p, int dim_x
     free(vt);
     free(ct);
     return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Dye visualiser: restates the arithmetic of the sketch's draw task,
+ * ESP32-fluid-simulation.ino:116-176 -- SCALING x SCALING bilinear up-scale of every cell block
+ * by strength-reduced lerps (c += dc, :134-161), float -> UQ32 narrowing (:168), RGB565 pack
+ * (:170-172) and optional byte swap (:173).  PARITY UNPINNED: the .ino cannot be compiled here
+ * (Arduino core / TFT_eSPI / FreeRTOS), so this restatement is checked by reading only.
+ *
+ * Screen geometry (ino:116-117,164,180): sim index i (fast axis, dim_x) runs down the screen,
+ * sim index j (dim_y) runs across; image = scaling*(dim_x-1) rows of scaling*(dim_y-1) pixels.
+ * The sketch re-uses a block's right edge as the next block's left edge (:139-143); recomputing
+ * the left edge from its two corner texels performs the identical operations.               */
+ORC_API void orc_render_rgb565(uint16_t *image, const uint32_t *colour, int dim_x, int dim_y,
+                               int scaling, int byteswap)
+{
+    const float inv = 1.0f / (float)scaling;
+    const int width = scaling * (dim_y - 1);
+    int i, j, ii, jj, k;
+    for (i = 0; i < dim_x - 1; ++i) {
+        for (j = 0; j < dim_y - 1; ++j) {
+            const uint32_t *t1 = colour + 3 * ((long)dim_x * j + i);           /* (i,   j)   */
+            const uint32_t *t2 = colour + 3 * ((long)dim_x * (j + 1) + i);     /* (i,   j+1) */
+            const uint32_t *t3 = t1 + 3;                                       /* (i+1, j)   */
+            const uint32_t *t4 = t2 + 3;                                       /* (i+1, j+1) */
+            for (ii = 0; ii < scaling; ++ii) {
+                for (jj = 0; jj < scaling; ++jj) {
+                    uint32_t raw[3];
+                    uint16_t px;
+                    for (k = 0; k < 3; ++k) {
+                        float l = uq32_to_float(t1[k]), r = uq32_to_float(t2[k]), c;
+                        const float dl = (uq32_to_float(t3[k]) - l) * inv;
+                        const float dr = (uq32_to_float(t4[k]) - r) * inv;
+                        float dc;
+                        int n;
+                        for (n = 0; n < ii; ++n) { l += dl; r += dr; }
+                        c = l;
+                        dc = (r - l) * inv;
+                        for (n = 0; n < jj; ++n) c += dc;
+                        raw[k] = uq32_from_float(c);
+                    }
+                    px = (uint16_t)(((raw[0] & 0xF8000000u) >> 16) | ((raw[1] & 0xFC000000u) >> 21) |
+                                    ((raw[2] & 0xF8000000u) >> 27));
+                    if (byteswap) px = (uint16_t)((px >> 8) | (px << 8));
+                    image[(long)(i * scaling + ii) * width + (j * scaling + jj)] = px;
+                }
+            }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ */

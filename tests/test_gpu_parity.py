@@ -252,3 +252,19 @@ def test_large_grid_properties(sfl):
         s.poisson_solve(1.0, iters, OMEGA)
         s.synchronize()
         assert not np.abs(s.download(sfl.capi.FIELD_PRESSURE)).any()
+
+
+@pytest.mark.parametrize("dim_x,dim_y,scaling", [(61, 81, 4), (5, 4, 4), (33, 17, 2), (40, 50, 3), (2, 2, 8)])
+def test_dye_visualiser_matches_oracle(sfl, oracle, dim_x, dim_y, scaling):
+    """draw-task arithmetic (ino:116-176) as a HIP kernel, bit-exact against the
+    oracle's restatement (itself unpinned: the .ino cannot be compiled here)."""
+    _, c, _ = random_fields(dim_x, dim_y, 12)
+    # use the top bits the 565 pack keeps, stay below the float -> uint32 UB range (SURVEY 5.1-6)
+    c = np.minimum(c.astype(np.uint64) * 2, 0xFE000000).astype(np.uint32)
+    with sfl.Solver(dim_x, dim_y) as s:
+        s.upload(sfl.capi.FIELD_COLOR, c)
+        for swap in (True, False):
+            got = s.render_rgb565(scaling, swap)
+            want = oracle.render_rgb565(c, scaling, swap)
+            assert got.shape == (scaling * (dim_x - 1), scaling * (dim_y - 1))
+            assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} pixels differ"
