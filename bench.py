@@ -85,6 +85,60 @@ def cpu_baseline(size, iters, budget_s=12.0):
                       f"g++/gcc -O2 -ffp-contract=off)"}
 
 
+def cpu_operator_times(dim_x, dim_y, iters):
+    """Per-operator wall time of the reference CPU path for ONE sim step (1 thread), ms."""
+    from oracle import loader
+    path = loader.reference() if loader.reference_available() else loader.port()
+    v = synthetic_velocity(dim_x, 0, dim_y)
+    c = synthetic_color(dim_x, 0, dim_y)
+    dt, om = np.float32(1 / 30.0), np.float32(1.96)
+    out = {}
+
+    def timed(name, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        out[name] = (time.perf_counter() - t0) * 1e3
+        return r
+    va = timed("advect_velocity", lambda: path.advect_vec2f(v, v, dt, True))
+    d = timed("calculate_divergence", lambda: path.divergence(va, 1.0))
+    p = timed("poisson_solve", lambda: path.poisson_solve(d, 1.0, iters, om))
+    vp = timed("subtract_gradient", lambda: path.subtract_gradient(va, p, 1.0))
+    timed("advect_color", lambda: path.advect_vec3uq32(c, vp, dt, False))
+    out["step"] = sum(out.values())
+    return {"grid": [dim_x, dim_y], "iters": iters, "kind": path.kind, "ms": out}
+
+
+def gpu_operator_times(s, capi, iters, reps=3):
+    """Per-operator HIP-event time of one sim step on this rank's slab, microseconds."""
+    dt, om = np.float32(1 / 30.0), np.float32(1.96)
+    ops = [("advect_velocity", lambda: s.advect_velocity(dt, True)),
+           ("calculate_divergence", lambda: s.calculate_divergence(1.0)),
+           ("poisson_solve", lambda: s.poisson_solve(1.0, iters, om)),
+           ("subtract_gradient", lambda: s.subtract_gradient(1.0)),
+           ("advect_color", lambda: s.advect_color(dt, False))]
+    out = {}
+    for name, fn in ops:
+        fn()
+        best = None
+        for _ in range(reps):
+            s.timer_start()
+            fn()
+            ms = s.timer_stop()
+            best = ms if best is None else min(best, ms)
+        out[name] = best * 1e3
+    return out
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def pmc_traffic(size, fuse, lane_cells, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json), or None when no entry matches this exact configuration."""
@@ -232,6 +286,10 @@ def main():
         else:
             sim_sps = args.sim_steps / sim_t
 
+    op_us = None
+    if world == 1 and args.sim_steps > 0:
+        op_us = gpu_operator_times(s, capi, iters)
+
     if rank == 0:
         cells = size * dim_y
         value = cells * iters * args.steps / elapsed
@@ -263,12 +321,18 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "sim_steps_per_sec": sim_sps,
+            "sim_step_per_operator_us": op_us,
             **({"sim_steps_note": sim_note} if sim_note else {}),
             "device": name,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(size, iters)  # always the square headline grid
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["host_cpu"] = host_cpu_model()
+            # the other half of SURVEY 8(d): the reference's per-operator times for one sim step,
+            # in full at the two small BASELINE configs (C1 as 61 x 81, C2)
+            out["cpu_baseline"]["sim_step_per_operator"] = [cpu_operator_times(61, 81, 20),
+                                                            cpu_operator_times(2048, 2048, 40)]
         print(json.dumps(out), flush=True)
 
     barrier()
