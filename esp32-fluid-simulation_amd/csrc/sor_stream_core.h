@@ -189,14 +189,18 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     }
 }
 
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int... Us>
+// One trip = RING consecutive iterations, fully unrolled.  FULL trips are straight-line code (no
+// branch between iterations: with a branch the compiler's wait-count pass loses track of the
+// loads in flight and drains them all -- s_waitcnt vmcnt(0) -- once per trip); only the last,
+// partial trip of a tile checks after every iteration whether the remaining rows still need to
+// enter.
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, bool PARTIAL, int... Us>
 SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                          const EdgeCell<B> &ecb, int y, int out_begin, int out_end,
                          std::integer_sequence<int, Us...>)
 {
-    // rows at or beyond y_stop need not enter: leave the unrolled body early on the last trip
     const int y_stop = out_end + NS;
-    (void)((y + Us < y_stop &&
+    (void)(((!PARTIAL || y + Us < y_stop) &&
             (iterate<B, NS, EDGE, DX1, ZERO_IN, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end),
              true)) && ...);
 }
@@ -222,11 +226,12 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 #pragma unroll
     for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
 
-    while (y < y_stop) {
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN>(bk, pp, c, eca, ecb, y, out_begin, out_end,
-                                                std::make_integer_sequence<int, RING>{});
-        y += RING;
-    }
+    for (; y + RING <= y_stop; y += RING)
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, false>(bk, pp, c, eca, ecb, y, out_begin, out_end,
+                                                       std::make_integer_sequence<int, RING>{});
+    if (y < y_stop)
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, true>(bk, pp, c, eca, ecb, y, out_begin, out_end,
+                                                      std::make_integer_sequence<int, RING>{});
 }
 
 // ---- tiling arithmetic shared by the launcher, the kernel and the emulator -----------------
