@@ -120,3 +120,35 @@ def test_domain_for_each_runs_user_expressions_on_the_device(tmp_path, oracle):
     subprocess.run([str(exe), str(fin), str(fout)], check=True)
     got = np.fromfile(fout, np.float32).reshape(dim_y, dim_x)
     assert_bit_equal(got, oracle.divergence(v, 1.0), "domain_for_each divergence")
+
+
+@pytest.mark.gpu
+def test_c_abi_context_loop_with_forces(tmp_path, oracle):
+    """INTEGRATION.md section 3 as a plain C-ABI program: resident fields, queued forces, sfl_step."""
+    subprocess.run(["make", "-C", CPP, "dropin"], check=True, stdout=subprocess.DEVNULL)
+    dim_x, dim_y, iters, steps = 96, 72, 9, 3
+    v, c = oracle.lcg_fields(dim_x, dim_y, 99, 50.0)
+    cells = np.array([[5, 6], [50, 40], [95, 71]], np.int32)
+    fv = np.array([[30.0, -20.0], [-15.5, 8.25], [3.0, 4.0]], np.float32)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("4i", dim_x, dim_y, iters, len(cells)))
+        f.write(v.tobytes()); f.write(c.tobytes()); f.write(cells.tobytes()); f.write(fv.tobytes())
+    subprocess.run([os.path.join(CPP, "context_loop"), str(fin), str(steps), str(fout)], check=True)
+    raw = open(fout, "rb").read()
+    n = dim_x * dim_y
+    got_v = np.frombuffer(raw, np.float32, 2 * n, 0).reshape(dim_y, dim_x, 2)
+    got_p = np.frombuffer(raw, np.float32, n, 8 * n).reshape(dim_y, dim_x)
+    got_c = np.frombuffer(raw, np.uint32, 3 * n, 12 * n).reshape(dim_y, dim_x, 3)
+    dt, omega = np.float32(1 / 30.0), np.float32(1.96)
+    for s in range(steps):
+        va = oracle.advect_vec2f(v, v, dt, True)
+        if s == 0:
+            for (i, j), u in zip(cells, fv):
+                va[j, i] = u
+        d = oracle.divergence(va, 1.0)
+        p = oracle.poisson_solve(d, 1.0, iters, omega)
+        v = oracle.subtract_gradient(va, p, 1.0)
+        c = oracle.advect_vec3uq32(c, v, dt, False)
+    for name, a, b in (("v", got_v, v), ("p", got_p, p), ("colour", got_c, c)):
+        assert_bit_equal(a, b, f"C-ABI context loop: {name}")

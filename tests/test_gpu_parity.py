@@ -268,3 +268,48 @@ def test_dye_visualiser_matches_oracle(sfl, oracle, dim_x, dim_y, scaling):
             want = oracle.render_rgb565(c, scaling, swap)
             assert got.shape == (scaling * (dim_x - 1), scaling * (dim_y - 1))
             assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} pixels differ"
+
+
+def test_api_error_paths(sfl):
+    """Status codes instead of crashes: options, sizes, states (the reference checks nothing)."""
+    cap = sfl.capi
+    with sfl.Solver(32, 16) as s:
+        for opt, bad in ((cap.OPT_SOR_KERNEL, 3), (cap.OPT_SOR_FUSE, 7), (cap.OPT_SOR_FUSE, 18),
+                         (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_ADVECT_HALO, 0), (cap.OPT_SOR_HALO, 1),
+                         (99, 0)):
+            with pytest.raises(sfl.SflError) as e:
+                s.set_option(opt, bad)
+            assert e.value.code == cap.ERR_INVALID
+        with pytest.raises(ValueError):
+            s.upload(cap.FIELD_PRESSURE, np.zeros((16, 31), np.float32))
+        with pytest.raises(sfl.SflError) as e:
+            s.poisson_solve(1.0, -1, OMEGA)
+        assert e.value.code == cap.ERR_INVALID
+        with pytest.raises(sfl.SflError) as e:      # no communicator on a whole-domain context
+            s.comm_loopback(4)
+        assert e.value.code == cap.ERR_STATE
+    # a slab without a transport cannot exchange halos: clear state error, not a hang
+    with sfl.Solver(32, 64, 0, 0, 2) as slab:
+        slab.upload(cap.FIELD_DIVERGENCE, np.ones((32, 32), np.float32))
+        with pytest.raises(sfl.SflError) as e:
+            slab.poisson_solve(1.0, 4, OMEGA)
+        assert e.value.code == cap.ERR_STATE
+        with pytest.raises(sfl.SflError) as e:      # render needs the whole domain
+            slab.render_rgb565(2)
+        assert e.value.code == cap.ERR_STATE
+    with pytest.raises(sfl.SflError):               # more slabs than rows
+        sfl.Solver(8, 4, 0, 0, 5)
+
+
+def test_two_contexts_are_independent(sfl, oracle):
+    """No global mutable state: two contexts of different shapes interleave freely."""
+    _, _, d1 = random_fields(64, 40, 1)
+    _, _, d2 = random_fields(130, 33, 2)
+    with sfl.Solver(64, 40) as a, sfl.Solver(130, 33) as b:
+        a.upload(sfl.capi.FIELD_DIVERGENCE, d1)
+        b.upload(sfl.capi.FIELD_DIVERGENCE, d2)
+        a.poisson_solve(1.0, 5, OMEGA)
+        b.poisson_solve(1.0, 9, OMEGA)
+        a.synchronize(); b.synchronize()
+        assert_bit_equal(b.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d2, 1.0, 9, OMEGA), "b")
+        assert_bit_equal(a.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d1, 1.0, 5, OMEGA), "a")
