@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--lane-cells", type=int, default=0, help="cells per lane of the fused kernel (0 auto, 2, 4)")
     ap.add_argument("--sim-steps", type=int, default=3, help="full sim steps timed after the main region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse-projection", action="store_true",
+                    help="sim step: separate subtract_gradient and dye-advection kernels (A/B)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
@@ -207,6 +209,8 @@ def main():
         s.set_option(capi.OPT_SOR_ROWS, args.sor_rows)
     if args.lane_cells:
         s.set_option(capi.OPT_SOR_LANE_CELLS, args.lane_cells)
+    if args.no_fuse_projection:
+        s.set_option(capi.OPT_FUSE_PROJECTION, 0)
     if world > 1:
         uid = [sfl.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

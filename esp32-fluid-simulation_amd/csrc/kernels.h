@@ -33,6 +33,13 @@ hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_
                                   int valid_begin, int valid_end, float dt, bool no_slip,
                                   int *halo_flag);
 
+// subtract_gradient (finitediff.cpp:41-82) fused into the dye advection: every cell first projects
+// its OWN velocity (in place), then back-traces with it -- ino:276 + ino:282 in one pass over v.
+hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
+                                          float *vel, const float *pressure, Slab g, int g_begin,
+                                          int g_end, int valid_begin, int valid_end, float dt,
+                                          bool no_slip, int *halo_flag, float two_dx_inv);
+
 // ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
 hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
                              int g_end, float two_dx_inv);

@@ -101,7 +101,7 @@ struct sfl_context {
     int d_force_cap = 0;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_transport = 0, opt_sor_lane_cells = 0, opt_sor_halo = 0;
+        opt_transport = 0, opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -546,6 +546,9 @@ int sfl_set_option(sfl_context *c, int option, int value)
         case SFL_OPT_TRANSPORT:
             c->opt_transport = value;
             return SFL_OK;
+        case SFL_OPT_FUSE_PROJECTION:
+            c->opt_fuse_projection = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -571,6 +574,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_TRANSPORT: *value = c->opt_transport; return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
+        case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -801,6 +805,30 @@ static int apply_queued_forces(sfl_context *c)
     return SFL_OK;
 }
 
+// ino:276 + ino:281-287 in one pass: project each cell's own velocity, advect the dye with it.
+static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
+{
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+        SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+        SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    }
+    SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, 1));
+    SFL_TRY(exchange(peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
+        HIP_TRY(sfl::launch_project_advect_vec3uq32(
+            c->stream, c->col_tmp, c->col, c->vel, c->p, c->geom, c->g0, c->g1, clip_lo(c, c->g0 - h),
+            clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? c->halo_flag : nullptr, two_dx_inv));
+        std::swap(c->col, c->col_tmp);  // ino:286
+    }
+    return SFL_OK;
+}
+
 int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
@@ -808,8 +836,12 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
     for (sfl_context *c : peers_of(ctx)) SFL_TRY(apply_queued_forces(c));  // ino:264-269
     SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
     SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));     // ino:275
-    SFL_TRY(sfl_subtract_gradient(ctx, dx));               // ino:276
-    SFL_TRY(sfl_advect_color(ctx, dt, 0));                 // ino:281-287
+    if (ctx->opt_fuse_projection) {
+        SFL_TRY(project_and_advect_color(ctx, dt, dx));    // ino:276 + ino:281-287, one pass over v
+    } else {
+        SFL_TRY(sfl_subtract_gradient(ctx, dx));           // ino:276
+        SFL_TRY(sfl_advect_color(ctx, dt, 0));             // ino:281-287
+    }
     return SFL_OK;
 }
 

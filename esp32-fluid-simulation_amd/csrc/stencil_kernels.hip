@@ -142,16 +142,34 @@ __device__ __forceinline__ uint32_t uq_mix(float t, uint32_t a, uint32_t b)
     return uq_narrow(mix1(t, uq_widen(a), uq_widen(b)));
 }
 
-template <bool NO_SLIP>
+// FUSE_GRAD: the projection step subtract_gradient (finitediff.cpp:41-82) is applied to the
+// cell's own velocity first -- the dye back-trace reads ONLY vel[ij] (advect.h:81), so the
+// projected velocity can be produced here, written back in place and used at once; this saves
+// the separate pass over v of ino:276 followed by ino:282 (same arithmetic, same results).
+template <bool NO_SLIP, bool FUSE_GRAD>
 __global__ void __launch_bounds__(kBlock)
-advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, const float2 *vel, Slab g,
-                       int g_begin, int valid_begin, int valid_end, float dt, int *halo_flag)
+advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 *vel, Slab g,
+                       int g_begin, int valid_begin, int valid_end, float dt, int *halo_flag,
+                       const float *__restrict__ pressure, float two_dx_inv)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int gj = g_begin + blockIdx.y;
     if (i >= g.dim_x) return;
     const size_t c = lcell(g, i, gj);
-    const float2 u = vel[c];
+    float2 u = vel[c];
+    if (FUSE_GRAD) {
+        const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+        const float pc = pressure[c];
+        const float pw = (i > 0) ? pressure[c - 1] : pc;
+        const float pe = (i < i_max) ? pressure[c + 1] : pc;
+        const float ps = (gj > 0) ? pressure[c - g.dim_x] : pc;
+        const float pn = (gj < j_max) ? pressure[c + g.dim_x] : pc;
+        const float gx = (pe - pw) * two_dx_inv;
+        const float gy = (pn - ps) * two_dx_inv;
+        u.x = u.x - gx;
+        u.y = u.y - gy;
+        vel[c] = u;
+    }
     const float si = (float)i - u.x * dt;
     const float sj = (float)gj - u.y * dt;
     const SrcPos s = classify(si, sj, g.dim_x, g.gdim_y);
@@ -359,13 +377,30 @@ hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_
 {
     if (g_end <= g_begin) return hipSuccess;
     const dim3 grid = grid_cells(g.dim_x, g_end - g_begin);
-    auto *vi = reinterpret_cast<const float2 *>(vel);
+    auto *vi = reinterpret_cast<float2 *>(const_cast<float *>(vel));  // read-only without FUSE_GRAD
     if (no_slip)
-        advect_vec3uq32_kernel<true><<<grid, kBlock, 0, s>>>(next_p, p, vi, g, g_begin,
-                                                             valid_begin, valid_end, dt, halo_flag);
+        advect_vec3uq32_kernel<true, false><<<grid, kBlock, 0, s>>>(
+            next_p, p, vi, g, g_begin, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
     else
-        advect_vec3uq32_kernel<false><<<grid, kBlock, 0, s>>>(next_p, p, vi, g, g_begin,
-                                                              valid_begin, valid_end, dt, halo_flag);
+        advect_vec3uq32_kernel<false, false><<<grid, kBlock, 0, s>>>(
+            next_p, p, vi, g, g_begin, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
+                                          float *vel, const float *pressure, Slab g, int g_begin,
+                                          int g_end, int valid_begin, int valid_end, float dt,
+                                          bool no_slip, int *halo_flag, float two_dx_inv)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const dim3 grid = grid_cells(g.dim_x, g_end - g_begin);
+    auto *vi = reinterpret_cast<float2 *>(vel);
+    if (no_slip)
+        advect_vec3uq32_kernel<true, true><<<grid, kBlock, 0, s>>>(
+            next_p, p, vi, g, g_begin, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
+    else
+        advect_vec3uq32_kernel<false, true><<<grid, kBlock, 0, s>>>(
+            next_p, p, vi, g, g_begin, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
     return hipGetLastError();
 }
 

@@ -67,6 +67,8 @@ extern "C" {
 #define SFL_OPT_SOR_HALO 6     /* rows of p exchanged per superstep on a slab (kernel 2): 0 = auto
                                   (64 rows on slabs of >= 1024 rows, else 32), else fuse..64; larger = fewer, larger exchanges and more
                                   redundantly recomputed ghost rows                             */
+#define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied inside
+                                  the dye-advection kernel (one pass over v), 0 = two kernels   */
 #define SFL_OPT_SOR_LANE_CELLS 5 /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
                                   width), 4 = packed fp32 (dim_x % 4 == 0; else falls back to 2) */
 

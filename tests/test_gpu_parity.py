@@ -359,6 +359,24 @@ def test_randomised_configurations_vs_oracle(sfl, oracle):
         assert_bit_equal(got, want, tag)
 
 
+def test_step_with_and_without_fused_projection(sfl, oracle):
+    """sfl_step applies subtract_gradient inside the dye-advection kernel by default; the
+    two-kernel form must give the same bits (both equal the oracle)."""
+    v, c, _ = random_fields(150, 90, 31, 70.0)
+    want = oracle.step(v, c, DT, 1.0, 6, OMEGA)
+    for fuse in (1, 0):
+        with sfl.Solver(150, 90) as s:
+            s.set_option(sfl.capi.OPT_FUSE_PROJECTION, fuse)
+            s.upload(sfl.capi.FIELD_VELOCITY, v)
+            s.upload(sfl.capi.FIELD_COLOR, c)
+            s.step(DT, 1.0, 6, OMEGA)
+            s.synchronize()
+            got = (s.download(sfl.capi.FIELD_VELOCITY), s.download(sfl.capi.FIELD_DIVERGENCE),
+                   s.download(sfl.capi.FIELD_PRESSURE), s.download(sfl.capi.FIELD_COLOR))
+        for name, a, b in zip(("v", "div", "p", "colour"), got, want):
+            assert_bit_equal(a, b, f"fuse_projection={fuse}: {name}")
+
+
 def test_long_run_stays_bit_identical(hip, oracle):
     """30 consecutive sim steps (the sketch's parameters: 10 iterations, omega 1.96, dt 1/30) on the
     ESP32 domain: no drift between the GPU path and the oracle, bit for bit, at every step."""
