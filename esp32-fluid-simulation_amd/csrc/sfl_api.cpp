@@ -101,7 +101,7 @@ struct sfl_context {
     int d_force_cap = 0;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_transport = 0, opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1;
+        opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -544,8 +544,7 @@ int sfl_set_option(sfl_context *c, int option, int value)
             c->opt_sor_rows = value;
             return SFL_OK;
         case SFL_OPT_TRANSPORT:
-            c->opt_transport = value;
-            return SFL_OK;
+            return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
@@ -571,7 +570,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_FUSE: *value = c->opt_sor_fuse; return SFL_OK;
         case SFL_OPT_ADVECT_HALO: *value = c->opt_advect_halo; return SFL_OK;
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
-        case SFL_OPT_TRANSPORT: *value = c->opt_transport; return SFL_OK;
+        case SFL_OPT_TRANSPORT: *value = c->comm ? 1 : (c->group ? 2 : 0); return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;

@@ -55,22 +55,23 @@ extern "C" {
 #define SFL_FIELD_DIVERGENCE 2 /* float           div_v          (ino:272)                   */
 #define SFL_FIELD_PRESSURE 3   /* float           p              (ino:273)                   */
 
-/* ---- tunables (sfl_set_option) ------------------------------------------------------ */
-#define SFL_OPT_SOR_KERNEL 0   /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
-                                  2 = fused multi-half-sweep streaming kernel                   */
-#define SFL_OPT_SOR_FUSE 1     /* half-sweeps fused per launch by kernel 2: even, 2..16, or 0 =
-                                  auto (16 on slabs of >= 3000 rows, else 8)                    */
-#define SFL_OPT_ADVECT_HALO 2  /* rows of advected-field halo kept per side on a slab (>= 1)    */
-#define SFL_OPT_SOR_ROWS 3     /* output rows per wave chunk of kernel 2 (0 = auto)             */
-#define SFL_OPT_TRANSPORT 4    /* 0 = RCCL send/recv, 1 = in-process copies between the virtual
-                                  ranks of a sfl_group (single device; test / bring-up)         */
-#define SFL_OPT_SOR_HALO 6     /* rows of p exchanged per superstep on a slab (kernel 2): 0 = auto
-                                  (64 rows on slabs of >= 1024 rows, else 32), else fuse..64; larger = fewer, larger exchanges and more
-                                  redundantly recomputed ghost rows                             */
-#define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied inside
-                                  the dye-advection kernel (one pass over v), 0 = two kernels   */
-#define SFL_OPT_SOR_LANE_CELLS 5 /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
-                                  width), 4 = packed fp32 (dim_x % 4 == 0; else falls back to 2) */
+/* ---- tunables (sfl_set_option / sfl_get_option) ------------------------------------------ */
+#define SFL_OPT_SOR_KERNEL 0      /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
+                                     2 = fused multi-pass streaming kernel                       */
+#define SFL_OPT_SOR_FUSE 1        /* colour passes fused per launch by kernel 2: even, 2..16, or
+                                     0 = auto (16 on slabs of >= 3000 rows, else 8)              */
+#define SFL_OPT_ADVECT_HALO 2     /* rows of advected-field halo kept per side on a slab (>= 1)  */
+#define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
+#define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
+                                     1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link)  */
+#define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
+                                     width), 4 = packed fp32 (dim_x % 4 == 0; else falls back)    */
+#define SFL_OPT_SOR_HALO 6        /* rows of p exchanged per superstep on a slab (kernel 2): 0 =
+                                     auto (64 on slabs of >= 1024 rows, else 32), else fuse..64;
+                                     larger = fewer, larger exchanges, more recomputed ghost rows */
+#define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied
+                                     inside the dye-advection kernel (one pass over v), 0 = two
+                                     kernels                                                     */
 
 typedef struct sfl_context sfl_context;
 
@@ -124,10 +125,9 @@ SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fus
 
 /* Pass plan of one poisson_solve: 2*iters half-sweeps are executed as `*n_passes` launches of
  * at most `fuse` half-sweeps each (the last one may be shorter); passes[k] receives the
- * number of half-sweeps of launch k when passes != NULL (capacity cap).  On a slab, every
- * pass after the first is preceded by one halo exchange of passes[k] rows of p per side;
- * the first needs none because p starts at zero everywhere (poisson.cpp:117-119).
- * Pure arithmetic, no GPU needed.                                                           */
+ * number of half-sweeps of launch k when passes != NULL (capacity cap).  How these launches
+ * interleave with halo exchanges on a slab is sfl_plan_poisson's business.  Pure arithmetic,
+ * no GPU needed.                                                                            */
 SFL_API int sfl_sor_pass_plan(int iters, int fuse, int *n_passes, int *passes, int cap);
 
 /* =====================================================================================
