@@ -387,3 +387,47 @@ def test_long_run_stays_bit_identical(hip, oracle):
         vo, do, po, co = oracle.step(vo, co, DT, 1.0, 10, OMEGA)
         assert_bit_equal(v, vo, f"step {step} v")
         assert_bit_equal(c, co, f"step {step} colour")
+
+
+@pytest.mark.parametrize("dim_x,dim_y", [(5000, 3000), (8191, 1025), (4098, 4097), (16384, 520), (130, 9000)])
+def test_large_irregular_shapes_vs_oracle(sfl, oracle, dim_x, dim_y):
+    """Large grids whose sides are odd / not tile multiples / very flat / very tall: full sim
+    step and a deeper solve against the oracle (auto fuse depth, auto tiling, both stencil forms)."""
+    rng = np.random.default_rng(dim_x * 7 + dim_y)
+    v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * 60).astype(np.float32)
+    c = rng.integers(0, 2 ** 31, (dim_y, dim_x, 3), dtype=np.uint32)
+    hp = sfl.HostPath()
+    got = hp.step(v, c, DT, 1.0, 3, OMEGA)
+    want = oracle.step(v, c, DT, 1.0, 3, OMEGA)
+    for name, a, b in zip(("v", "div", "p", "colour"), got, want):
+        assert_bit_equal(a, b, f"{dim_x}x{dim_y} step: {name}")
+    d = want[1]
+    assert_bit_equal(hp.poisson_solve(d, 1.0, 9, OMEGA), oracle.poisson_solve(d, 1.0, 9, OMEGA),
+                     f"{dim_x}x{dim_y} 9-iteration solve")
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks):
+    """1024 x 2048 split into 2 / 4 slabs with every option on auto (fuse 8, halo 64 resp. 32,
+    supersteps of several launches, extended output ranges): the production multi-GPU schedule
+    with in-process copies in place of RCCL, against the oracle."""
+    dim_x, dim_y, iters = 1024, 2048, 20
+    rng = np.random.default_rng(5)
+    d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[0].last_solve_info()
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+        assert slabs[0].get_option(sfl.capi.OPT_TRANSPORT) == 2
+    finally:
+        for s in slabs:
+            s.close()
+    assert_bit_equal(got, want, f"{nranks} slabs, auto settings")
+    assert info["fuse"] == 8 and info["launches"] == 5
+    assert info["exchanges"] == (1 if nranks == 2 else 2)   # rhs once (+ one p exchange at halo 32)
