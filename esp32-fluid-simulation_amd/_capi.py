@@ -98,6 +98,7 @@ SIGNATURES = {
     "sfl_subtract_gradient": (_i, [_ctx, _f]),
     "sfl_step": (_i, [_ctx, _f, _f, _i, _f]),
     "sfl_queue_forces": (_i, [_ctx, _pi, _pf, _i]),
+    "sfl_setup_sketch_fields": (_i, [_ctx]),
     "sfl_render_rgb565": (_i, [_ctx, _i, _i, C.POINTER(C.c_uint16), _sz]),
     "sfl_synchronize": (_i, [_ctx]),
     "sfl_timer_start": (_i, [_ctx]),

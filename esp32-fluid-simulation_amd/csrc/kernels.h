@@ -88,6 +88,10 @@ hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_
 hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
                                const int *cells_ij, const float *vel_xy, int n);
 
+// Initial condition of the sketch's setup() (ino:196-241): zero velocity, three dye sectors, two
+// in-place sequential 1-2-1 blurs; WHOLE-DOMAIN arrays.
+hipError_t launch_setup_sketch_fields(hipStream_t s, float *v, uint32_t *colour, int dim_x, int dim_y);
+
 // Dye visualiser (draw task, ino:116-176): scaling x scaling bilinear up-scale + RGB565 pack of a
 // WHOLE-DOMAIN colour field; image = scaling*(dim_x-1) rows of scaling*(dim_y-1) pixels (device).
 hipError_t launch_render_rgb565(hipStream_t s, uint16_t *image, const uint32_t *colour, int dim_x,

@@ -844,6 +844,17 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
     return SFL_OK;
 }
 
+int sfl_setup_sketch_fields(sfl_context *c)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (c->nranks != 1) return fail(SFL_ERR_STATE, "setup needs a whole-domain context (slab %d/%d)", c->rank, c->nranks);
+    SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+    SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+    SFL_TRY(use_device(c));
+    HIP_TRY(sfl::launch_setup_sketch_fields(c->stream, c->vel, c->col, c->dim_x, c->gdim_y));
+    return SFL_OK;
+}
+
 int sfl_render_rgb565(sfl_context *c, int scaling, int byteswap, uint16_t *host_image, size_t bytes)
 {
     if (!c || !host_image) return fail(SFL_ERR_INVALID, "NULL argument");

@@ -327,6 +327,53 @@ render_rgb565_kernel(uint16_t *__restrict__ image, const uint32_t *__restrict__ 
     image[(size_t)sy * width + sx] = px;
 }
 
+// ---- initial condition of the sketch's setup() (ino:196-241) ------------------
+// float -> UQ32 with SATURATION for values >= 2^32: the sketch converts UINT32_MAX (2^32 as a
+// float) and blurred sums that reach 2^32, which is undefined behaviour in C++; the ESP32's and
+// this GPU's conversion instructions saturate, and so does the oracle's restatement.
+__device__ __forceinline__ uint32_t uq_narrow_sat(float x)
+{
+    const float y = x + 0.5f;
+    return y >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)y;
+}
+
+// three 120-degree dye sectors (ino:204-218) + zero velocity (ino:197-201), one thread per cell
+__global__ void __launch_bounds__(kBlock)
+setup_sectors_kernel(float2 *__restrict__ v, uint32_t *__restrict__ colour, int dim_x, int dim_y)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x, j = blockIdx.y;
+    if (i >= dim_x) return;
+    const size_t c = (size_t)dim_x * j + i;
+    v[c] = make_float2(0.0f, 0.0f);
+    const double third_pi = 3.1415926535897932384626433832795 / 3;  // Arduino's PI / 3
+    const float angle = atan2f((float)(-(i - dim_x / 2)), (float)(j - dim_y / 2));
+    const int sector = ((double)angle < -third_pi) ? 0 : ((double)angle < third_pi) ? 1 : 2;
+    for (int k = 0; k < 3; ++k)
+        colour[3 * c + k] = uq_narrow_sat(k == sector ? (float)4294967295u : 0.0f);
+}
+
+// The sketch's blurs run IN PLACE and sequentially (ino:219-241): along the blurred axis the
+// previous cell is already blurred, the next one is not -- a recurrence.  Lines are independent:
+// one thread per line.  ALONG_J: line = fixed i, walks j (stride dim_x); else fixed j, walks i.
+template <bool ALONG_J>
+__global__ void __launch_bounds__(kBlock)
+setup_blur_kernel(uint32_t *colour, int dim_x, int dim_y)
+{
+    const int line = blockIdx.x * kBlock + threadIdx.x;
+    const int n_lines = ALONG_J ? dim_x : dim_y, len = ALONG_J ? dim_y : dim_x;
+    if (line >= n_lines) return;
+    const size_t stride = ALONG_J ? (size_t)dim_x * 3 : 3;
+    uint32_t *c = colour + (ALONG_J ? (size_t)line * 3 : (size_t)line * dim_x * 3);
+    for (int t = 0; t < len; ++t, c += stride) {
+        const uint32_t *prev = (t == 0) ? c : c - stride;
+        const uint32_t *next = (t == len - 1) ? c : c + stride;
+        for (int k = 0; k < 3; ++k) {
+            const float s = (0.25f * uq_widen(prev[k]) + 0.5f * uq_widen(c[k])) + 0.25f * uq_widen(next[k]);
+            c[k] = uq_narrow_sat(s);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 zero_rows_kernel(float *f, size_t first, size_t count)
 {
@@ -449,6 +496,15 @@ hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_
     const size_t want = (count + kBlock - 1) / kBlock;
     const int blocks = (int)(want < 4096 ? want : 4096);
     zero_rows_kernel<<<blocks, kBlock, 0, s>>>(f, first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_setup_sketch_fields(hipStream_t s, float *v, uint32_t *colour, int dim_x, int dim_y)
+{
+    setup_sectors_kernel<<<dim3((dim_x + kBlock - 1) / kBlock, dim_y), kBlock, 0, s>>>(
+        reinterpret_cast<float2 *>(v), colour, dim_x, dim_y);
+    setup_blur_kernel<true><<<(dim_x + kBlock - 1) / kBlock, kBlock, 0, s>>>(colour, dim_x, dim_y);
+    setup_blur_kernel<false><<<(dim_y + kBlock - 1) / kBlock, kBlock, 0, s>>>(colour, dim_x, dim_y);
     return hipGetLastError();
 }
 

@@ -174,6 +174,10 @@ class Solver:
             self._h, cells.ctypes.data_as(C.POINTER(C.c_int)),
             vel.ctypes.data_as(C.POINTER(C.c_float)), len(cells)))
 
+    def setup_sketch_fields(self):
+        """Velocity = 0, dye = the sketch's blurred three-sector pattern (setup(), ino:196-241)."""
+        capi.check(self._lib.sfl_setup_sketch_fields(self._h))
+
     def render_rgb565(self, scaling: int = 4, byteswap: bool = True) -> np.ndarray:
         """Dye field -> RGB565 image, uint16[scaling*(dim_x-1), scaling*(dim_y-1)] (ino:116-176)."""
         img = np.empty((scaling * (self.dim_x - 1), scaling * (self.dim_y - 1)), np.uint16)

@@ -47,13 +47,18 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--scaling", type=int, default=2)
     ap.add_argument("--out", default="frames")
+    ap.add_argument("--sketch-init", action="store_true",
+                    help="initial condition from sfl_setup_sketch_fields (ino:196-241) instead of numpy")
     args = ap.parse_args()
     sfl = importlib.import_module("esp32-fluid-simulation_amd")
     dim_x, dim_y = args.size
     os.makedirs(args.out, exist_ok=True)
     with sfl.Solver(dim_x, dim_y) as s:
-        s.upload(sfl.capi.FIELD_VELOCITY, np.zeros((dim_y, dim_x, 2), np.float32))
-        s.upload(sfl.capi.FIELD_COLOR, three_sectors(dim_x, dim_y))
+        if args.sketch_init:   # the sketch's own setup(): ino:196-241, on the GPU
+            s.setup_sketch_fields()
+        else:
+            s.upload(sfl.capi.FIELD_VELOCITY, np.zeros((dim_y, dim_x, 2), np.float32))
+            s.upload(sfl.capi.FIELD_COLOR, three_sectors(dim_x, dim_y))
         radius, speed = 0.3 * min(dim_x, dim_y), 0.15 * min(dim_x, dim_y) * 30
         for step in range(args.steps):
             a = 2 * math.pi * step / 90

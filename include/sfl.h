@@ -214,6 +214,13 @@ SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omeg
  * in SIMULATION coordinates (the sketch's x/y swap is the caller's business).               */
 SFL_API int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n);
 
+/* --- initial condition of the sketch (setup(), ino:196-241): velocity = 0; dye = three
+ *     120-degree sectors around the centre chosen by atan2f, then the sketch's two in-place
+ *     sequential 1-2-1 blur passes in UQ32.  The sketch pushes UINT32_MAX through float -> uint32
+ *     conversions that are undefined in C++; they SATURATE here (as on the ESP32).  Whole-domain
+ *     contexts only; asynchronous on the context's stream.                                   */
+SFL_API int sfl_setup_sketch_fields(sfl_context *ctx);
+
 /* --- dye visualiser (the arithmetic of the sketch's draw task, ino:116-176): every cell block
  *     is up-scaled `scaling` x `scaling` by the sketch's incremental lerps, narrowed to UQ32 and
  *     packed to RGB565 (byte-swapped like ino:173 when byteswap != 0).  `host_image` receives

@@ -130,6 +130,9 @@ class OraclePort(CpuPath):
         self._render = lib.orc_render_rgb565
         self._render.argtypes = [C.POINTER(C.c_uint16), _U, C.c_int, C.c_int, C.c_int, C.c_int]
         self._render.restype = None
+        self._setup = lib.orc_setup_fields
+        self._setup.argtypes = [_F, _U, C.c_int, C.c_int]
+        self._setup.restype = None
         self._fnv = lib.orc_fnv1a64
         self._fnv.argtypes = [C.c_void_p, C.c_size_t]
         self._fnv.restype = C.c_uint64
@@ -153,6 +156,13 @@ class OraclePort(CpuPath):
         self._render(img.ctypes.data_as(C.POINTER(C.c_uint16)), _up(colour), dim_x, dim_y, scaling,
                      int(byteswap))
         return img
+
+    def setup_fields(self, dim_x, dim_y):
+        """Initial condition of the sketch's setup() (ino:196-241; unpinned).  Returns (v, colour)."""
+        v = np.empty((dim_y, dim_x, 2), np.float32)
+        c = np.empty((dim_y, dim_x, 3), np.uint32)
+        self._setup(_fp(v), _up(c), dim_x, dim_y)
+        return v, c
 
     def lcg_fields(self, dim_x, dim_y, seed, vamp):
         v = np.empty((dim_y, dim_x, 2), np.float32)

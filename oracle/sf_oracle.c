@@ -19,6 +19,8 @@
  *                                            to a row range (used by the slab-sharding tests)
  *   orc_step                                 call order of ESP32-fluid-simulation.ino:252-287
  *                                            (no force injection, no RTOS hand-off)
+ *   orc_setup_fields                         initial condition of setup(), ino:196-241 (PARITY
+ *                                            UNPINNED; saturating float -> uint32 by definition)
  *   orc_render_rgb565                        draw-task arithmetic, ino:116-176 (PARITY UNPINNED:
  *                                            the .ino does not compile outside the Arduino core)
  *
@@ -396,6 +398,61 @@ ORC_API void orc_render_rgb565(uint16_t *image, const uint32_t *colour, int dim_
                     if (byteswap) px = (uint16_t)((px >> 8) | (px << 8));
                     image[(long)(i * scaling + ii) * width + (j * scaling + jj)] = px;
                 }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Initial condition of the sketch: restates setup(), ino:196-241 -- zero
+ * velocity (:197-201); dye = three 120-degree sectors chosen by atan2f (:204-218); two in-place,
+ * sequential 1-2-1 blur passes in UQ32, first along j (:219-229: the left neighbour is already
+ * blurred, the right one is not), then along i (:230-241).  PARITY UNPINNED (the .ino does not
+ * compile here).  One deliberate definition: the sketch feeds UINT32_MAX through float -> uint32
+ * conversions that are undefined behaviour in C++ (4294967295 rounds to 2^32 as a float,
+ * SURVEY 5.1-6,11); like the ESP32's and the GPU's conversion instructions this restatement
+ * SATURATES (x86 would wrap to 0).                                                          */
+static inline uint32_t uq32_from_float_sat(float x)
+{
+    const float y = x + 0.5f;
+    return y >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)y;
+}
+
+ORC_API void orc_setup_fields(float *v, uint32_t *colour, int dim_x, int dim_y)
+{
+    const double third_pi = 3.1415926535897932384626433832795 / 3;  /* Arduino's PI / 3 */
+    const int ci = dim_x / 2, cj = dim_y / 2;
+    int i, j, k;
+    for (long n = 0; n < 2L * dim_x * dim_y; ++n) v[n] = 0.0f;
+    for (i = 0; i < dim_x; ++i) {
+        for (j = 0; j < dim_y; ++j) {
+            const float angle = atan2f((float)(-(i - ci)), (float)(j - cj));
+            uint32_t *c = colour + 3 * ((long)dim_x * j + i);
+            const int sector = ((double)angle < -third_pi) ? 0 : ((double)angle < third_pi) ? 1 : 2;
+            for (k = 0; k < 3; ++k) c[k] = uq32_from_float_sat(k == sector ? (float)4294967295u : 0.0f);
+        }
+    }
+    for (i = 0; i < dim_x; ++i) {           /* blur along j, in place, increasing j */
+        for (j = 0; j < dim_y; ++j) {
+            uint32_t *c = colour + 3 * ((long)dim_x * j + i);
+            const uint32_t *l = (j == 0) ? c : c - 3 * (long)dim_x;
+            const uint32_t *r = (j == dim_y - 1) ? c : c + 3 * (long)dim_x;
+            for (k = 0; k < 3; ++k) {
+                const float s = (0.25f * uq32_to_float(l[k]) + 0.5f * uq32_to_float(c[k])) +
+                                0.25f * uq32_to_float(r[k]);
+                c[k] = uq32_from_float_sat(s);
+            }
+        }
+    }
+    for (i = 0; i < dim_x; ++i) {           /* blur along i, in place, increasing i */
+        for (j = 0; j < dim_y; ++j) {
+            uint32_t *c = colour + 3 * ((long)dim_x * j + i);
+            const uint32_t *t = (i == 0) ? c : c - 3;
+            const uint32_t *b = (i == dim_x - 1) ? c : c + 3;
+            for (k = 0; k < 3; ++k) {
+                const float s = (0.25f * uq32_to_float(t[k]) + 0.5f * uq32_to_float(c[k])) +
+                                0.25f * uq32_to_float(b[k]);
+                c[k] = uq32_from_float_sat(s);
             }
         }
     }

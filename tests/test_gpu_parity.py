@@ -431,3 +431,18 @@ def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks)
     assert_bit_equal(got, want, f"{nranks} slabs, auto settings")
     assert info["fuse"] == 8 and info["launches"] == 5
     assert info["exchanges"] == (1 if nranks == 2 else 2)   # rhs once (+ one p exchange at halo 32)
+
+
+@pytest.mark.parametrize("dim_x,dim_y", [(61, 81), (2, 2), (40, 7), (257, 130)])
+def test_sketch_initial_condition_matches_oracle(sfl, oracle, dim_x, dim_y):
+    """setup() (ino:196-241) on the GPU -- sectors by atan2f, then the two in-place
+    sequential UQ32 blurs -- bit-exact against the oracle's restatement (unpinned; saturating)."""
+    v, c = oracle.setup_fields(dim_x, dim_y)
+    with sfl.Solver(dim_x, dim_y) as s:
+        s.upload(sfl.capi.FIELD_VELOCITY, np.ones((dim_y, dim_x, 2), np.float32))
+        s.setup_sketch_fields()
+        s.synchronize()
+        assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), v, "velocity")
+        assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), c, "dye")
+    if min(dim_x, dim_y) > 8:   # sector interiors stay saturated / empty after the blurs
+        assert c.max() == 0xFFFFFFFF and c.min() == 0
