@@ -190,6 +190,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+        torch.cuda.set_device(local_rank)   # torch.cuda.synchronize() below must mean THIS rank's GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
