@@ -446,3 +446,16 @@ def test_sketch_initial_condition_matches_oracle(sfl, oracle, dim_x, dim_y):
         assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), c, "dye")
     if min(dim_x, dim_y) > 8:   # sector interiors stay saturated / empty after the blurs
         assert c.max() == 0xFFFFFFFF and c.min() == 0
+
+
+def test_headline_size_full_step_vs_oracle(hip, oracle):
+    """One whole sim step (all five operators, ino:252-287) on the 8192 x 8192 headline grid against
+    the oracle, every cell of every field (the oracle needs ~20 s for it on one core)."""
+    n = 8192
+    rng = np.random.default_rng(8192)
+    v = (rng.uniform(-1, 1, (n, n, 2)) * 100).astype(np.float32)
+    c = rng.integers(0, 2 ** 31, (n, n, 3), dtype=np.uint32)
+    got = hip.step(v, c, DT, 1.0, 2, OMEGA)
+    want = oracle.step(v, c, DT, 1.0, 2, OMEGA)
+    for name, a, b in zip(("v", "div", "p", "colour"), got, want):
+        assert_bit_equal(a, b, f"8192^2 step: {name}")
