@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 SOR_BYTES_PER_CELL_ITER = 16
+SOR_FLOPS_PER_CELL_ITER = 8    # one relaxation of an interior cell: 3 neighbour adds, rhs subtract,
+                               # scale by -1/4, two omega products and their sum (never fused);
+                               # SURVEY 8a13 counts 10: dx*d is exact at dx = 1, 1-omega is hoisted
+VALU_CLOCK_GHZ = 2.4           # MI355X max engine clock (MI355X_MICROARCH.md)
 
 
 def synthetic_velocity(dim_x, row_begin, row_end, seed=12345, vamp=100.0):
@@ -325,7 +329,16 @@ def main():
                          "traffic_source": pmc["source"] if pmc else None,
                          "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
                          "avg_launch_us": avg_launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # what actually bounds the temporally blocked kernel: the
+                         # reference's 8 unfused fp32 operations per relaxation (poisson.cpp:63-112;
+                         # contraction to FMA would change results) against one plain fp32 VALU
+                         # operation per lane per clock, 64 lanes x CUs x 2.4 GHz
+                         "valu": {"flops_per_cell_iter": SOR_FLOPS_PER_CELL_ITER,
+                                  "achieved": value / world * SOR_FLOPS_PER_CELL_ITER / 1e12,
+                                  "peak": cus * 64 * VALU_CLOCK_GHZ / 1e3, "unit": "TFLOP/s",
+                                  "frac": value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
+                                          / (cus * 64 * VALU_CLOCK_GHZ / 1e3)}},
             "sim_steps_per_sec": sim_sps,
             "sim_step_per_operator_us": op_us,
             **({"sim_steps_note": sim_note} if sim_note else {}),
