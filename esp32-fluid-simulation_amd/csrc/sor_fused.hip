@@ -291,13 +291,10 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         block = xcd * per + min(xcd, rem) + idx;  // bijective for every nblocks
     }
     const int tile = block * kWavesPerBlock + wave;
-    if (tile >= t.n_strips * t.n_chunks) return;
-    const int chunk = tile / t.n_strips;
-    const int strip = tile - chunk * t.n_strips;
-
-    const int x0 = sor::strip_x0(t, strip);
-    const int r0 = t.g_begin + chunk * t.rows_per_chunk;
-    const int r1 = min(r0 + t.rows_per_chunk, t.g_end);
+    if (tile >= t.n_tiles) return;
+    const sor::TileRect rect = sor::tile_rect(t, tile);
+    const int x0 = sor::strip_x0(t, rect.strip);
+    const int r0 = rect.r0, r1 = rect.r1;
 
     B bk;
     const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
@@ -314,7 +311,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
 
     sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
 
-    if (sor::tile_touches_boundary(t, strip, chunk, g.gdim_y)) {  // wave-uniform
+    if (sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
@@ -357,21 +354,24 @@ inline int device_simds()
     return cached;
 }
 
-// Output rows per wave tile.  Every tile costs about the same (rows streamed = rpc + 2 NS of
-// warm-up), a SIMD works through its tiles essentially one VALU stream at a time, so a launch
-// takes about ceil(tiles / SIMDs) * (rpc + 2 NS) row-steps -- provided each SIMD holds ~2+ waves
-// to cover DS / memory latency (measured on 8192 x {1024, 8192}, profiles/r01_rows_per_chunk.txt:
-// fewer than ~2 waves per SIMD costs 1.4x, 2..3 waves ~1.08x).  Pick the chunk count that
-// minimises that, never exceeding the resident-wave capacity by less than a full round.
-inline int auto_rows_per_chunk(int rows, int strips, int ns, int waves, int simds)
+// Output rows per interior wave tile (boundary tiles get fewer: sor::make_tiling).  Every tile
+// costs about the same (rows streamed = rpc + 2 NS of warm-up), a SIMD works through its tiles
+// essentially one VALU stream at a time, so a launch takes about ceil(tiles / SIMDs) * (rpc + 2 NS)
+// row-steps -- provided each SIMD holds ~2+ waves to cover DS / memory latency (measured on
+// 8192 x {1024, 8192}, profiles/r01_rows_per_chunk.txt: fewer than ~2 waves per SIMD costs 1.4x,
+// 2..3 waves ~1.08x).  Pick the chunk count that minimises that, never exceeding the
+// resident-wave capacity by less than a full round.
+template <class B>
+int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves, int simds)
 {
+    const int rows = g_end - g_begin;
     int best_rows = rows;
     double best_cost = 1e300;
     const int max_chunks = (rows + 7) / 8;
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
-        const int real_chunks = (rows + rpc - 1) / rpc;
-        const long tiles = (long)real_chunks * strips;
+        const long tiles = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
+                                            g_end, rpc, true).n_tiles;
         const double per_simd = (double)tiles / simds;
         const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
         const long rounds = (tiles + waves - 1) / waves;          // residency rounds
@@ -390,14 +390,13 @@ template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                           int g_begin, int g_end, SorParams prm, int rows_per_chunk)
 {
-    sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g_begin, g_end, 1);
     const int rpc = rows_per_chunk > 0
                         ? rows_per_chunk
-                        : auto_rows_per_chunk(g_end - g_begin, t.n_strips, NS,
-                                              resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
-    t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g_begin, g_end, rpc);
-    const int tiles = t.n_strips * t.n_chunks;
-    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+                        : auto_rows_per_chunk<B>(g, g_begin, g_end, NS,
+                                                 resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
+    const sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
+                                           g_end, rpc, true);
+    const int blocks = (t.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
     return hipGetLastError();
 }

@@ -165,12 +165,14 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge)
+               bool vec2, bool poison, bool force_edge, bool balance)
 {
     using namespace sfl::sor;
-    const Tiling t = make_tiling(NS, 128, 2, dim_x, g_begin, g_end, rows_per_chunk);
-    for (int chunk = 0; chunk < t.n_chunks; ++chunk) {
-        for (int strip = 0; strip < t.n_strips; ++strip) {
+    const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk, balance);
+    {
+        for (int tile = 0; tile < t.n_tiles; ++tile) {
+            const TileRect rect = tile_rect(t, tile);
+            const int strip = rect.strip;
             EmuBackend bk;
             bk.p_in = p_in;
             bk.d = d;
@@ -187,10 +189,9 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
             bk.poison_on = poison;
             bk.ring.assign((size_t)ring_rows(NS) * 2 * 64,
                            poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
-            const int r0 = g_begin + chunk * rows_per_chunk;
-            const int r1 = (r0 + rows_per_chunk < g_end) ? r0 + rows_per_chunk : g_end;
+            const int r0 = rect.r0, r1 = rect.r1;
             Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
-            const bool edge = force_edge || tile_touches_boundary(t, strip, chunk, gdim_y);
+            const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
             const bool dx1 = dx == 1.0f;
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
@@ -210,18 +211,18 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
 }  // namespace
 
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
-//        bit2 = force the EDGE path for every tile
+//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles)
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
               int lrows, int g_begin, int g_end, int ns, float dx, float omega,
               int rows_per_chunk, int flags)
 {
-    const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4;
+    const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
         run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                     rows_per_chunk, vec2, poison, force_edge);                              \
+                     rows_per_chunk, vec2, poison, force_edge, balance);                           \
         return 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
@@ -229,4 +230,29 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
     }
 #undef EMU_CASE
     return -2;
+}
+
+// Tiling property check: adds 1 to cover[row * dim_x + col] for every cell a tile of the launch
+// would store (its exact columns x its output rows) and returns the number of tiles; *n_edge
+// receives how many of them take the EDGE path.  A correct tiling leaves exactly 1 on every cell
+// of rows [g_begin, g_end) and 0 elsewhere.
+extern "C" __attribute__((visibility("default"))) int
+emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin, int g_end,
+                 int rows_per_chunk, int balance, int *cover, int *n_edge)
+{
+    using namespace sfl::sor;
+    const Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
+                                 balance != 0);
+    *n_edge = 0;
+    for (int tile = 0; tile < t.n_tiles; ++tile) {
+        const TileRect r = tile_rect(t, tile);
+        if (r.strip < 0 || r.strip >= t.n_strips || r.r0 >= r.r1) return -1;
+        if (tile_touches_boundary(t, r, gdim_y)) ++*n_edge;
+        const int x0 = strip_x0(t, r.strip);
+        const int lo = x0 + t.halo_cols, hi = x0 + t.tile_cols - t.halo_cols;
+        for (int y = r.r0; y < r.r1; ++y)
+            for (int x = (lo < 0 ? 0 : lo); x < (hi < dim_x ? hi : dim_x); ++x)
+                if (y >= 0 && y < gdim_y) ++cover[(size_t)y * dim_x + x];
+    }
+    return t.n_tiles;
 }

@@ -25,18 +25,22 @@ def emu():
     lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
     lib.emu_sor_fused.restype = C.c_int
 
+    lib.emu_tiling_cover.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.emu_tiling_cover.restype = C.c_int
+
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
-            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None):
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False):
         lrows, dim_x = d.shape
         gdim_y = lrows if gdim_y is None else gdim_y
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
         assert rc == 0
         return out
+    run.lib = lib
     return run
 
 
@@ -50,6 +54,7 @@ def test_fused_passes_from_zero(emu, oracle, dim_x, dim_y, ns):
     want = oracle.poisson_solve(d, 1.0, ns // 2, OMEGA)
     assert_bit_equal(emu(None, d, ns, rows=16), want, "auto edge")
     assert_bit_equal(emu(None, d, ns, rows=40, force_edge=True), want, "forced edge path")
+    assert_bit_equal(emu(None, d, ns, rows=16, uniform=True), want, "uniform tiling")
     if dim_x % 2 == 0:
         assert_bit_equal(emu(None, d, ns, rows=16, vec2=True), want, "vec2 access variant")
 
@@ -96,3 +101,33 @@ def test_slab_launch_matches_whole_domain(emu, oracle, nranks, ns):
         emu(local(p0, ns), local(d, ns - 1), ns, rows=20, gdim_y=dim_y, grow0=grow0, g_begin=g0,
             g_end=g1, out=out)
         assert_bit_equal(out[g0 - grow0:g1 - grow0], want[g0:g1], f"slab {r}/{nranks}")
+
+
+def test_tilings_partition_the_row_range(emu):
+    """Property of the product's tiling arithmetic (uniform and boundary-balanced, both lane
+    flavours): every cell of the launch's row range is stored by exactly one tile, nothing outside
+    it is touched, and balancing only ever shortens boundary tiles."""
+    rng = np.random.default_rng(11)
+    cases = [(16, 8192, 8192, 0, 8192, 234), (8, 8192, 8192, 1024, 2048, 38), (16, 300, 200, 0, 200, 200)]
+    for _ in range(150):
+        ns = int(rng.choice([2, 4, 8, 12, 16]))
+        dim_x, gdim_y = int(rng.integers(2, 700)), int(rng.integers(2, 400))
+        g_begin = int(rng.integers(0, gdim_y))
+        g_end = int(rng.integers(g_begin + 1, gdim_y + 1))
+        if rng.random() < 0.4:
+            g_begin, g_end = 0, gdim_y
+        cases.append((ns, dim_x, gdim_y, g_begin, g_end, int(rng.integers(1, g_end - g_begin + 1))))
+    for ns, dim_x, gdim_y, g_begin, g_end, rpc in cases:
+        for tile_cols, align in ((128, 2), (256, 4)):
+            counts = {}
+            for balance in (0, 1):
+                cover = np.zeros((gdim_y, dim_x), np.int32)
+                n_edge = C.c_int(0)
+                n = emu.lib.emu_tiling_cover(ns, tile_cols, align, dim_x, gdim_y, g_begin, g_end, rpc, balance,
+                                             cover.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n_edge))
+                tag = f"ns {ns} {dim_x}x{gdim_y} rows [{g_begin},{g_end}) rpc {rpc} cols {tile_cols} balance {balance}"
+                assert n > 0, tag
+                assert (cover[g_begin:g_end] == 1).all(), tag
+                assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
+                counts[balance] = n
+            assert counts[1] >= counts[0]
