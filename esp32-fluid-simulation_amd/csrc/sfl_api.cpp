@@ -254,17 +254,20 @@ sfl::SorParams sor_params(float dx, float omega)
     return prm;
 }
 
-// Fuse depth: explicit option, or auto from the slab size.  Measured on MI355X
-// (profiles/r01_rows_per_chunk.txt): big slabs are HBM / issue bound and want the deepest fusion
-// (16 passes per launch: 2.8 ms per 80-iteration solve at 8192^2 against 3.8 ms for 8; 16384 x 2048:
-// 3.9 ms per 200 iterations against 4.7 ms); small slabs are dominated by the 2 * NS warm-up rows
-// each tile re-streams, where 8 wins (8192 x 2048: 0.97 ms against 1.07 ms; 8192 x 1024: 0.54 against
-// 0.77).  The crossover sits near 24 M cells per slab (8192 x 4096 is a tie).  Every rank of a
-// group sees the same thinnest slab, so all ranks resolve the same value.
+// Fuse depth: explicit option, or auto from the slab size.  Measured on MI355X with the balanced
+// tiling (profiles/r01_rows_per_chunk.txt, ms per 80-iteration solve, fuse 8 / 12 / 16):
+// 8192 x 8192: 3.6 / 2.7 / 2.15; 8192 x 4096: 1.79 / 1.40 / 1.29; 8192 x 2048: 0.84 / 0.75 / 0.75;
+// 8192 x 1024: 0.51 / 0.50 / 0.51 (0.48 at 10); 8192 x 512: 0.39 / 0.42 / 0.45; 2048^2 (40 iterations):
+// 0.19 / 0.21 / 0.23.  Big slabs are VALU / HBM bound and want the deepest fusion; small ones are
+// dominated by the 2 * NS warm-up rows each tile re-streams.  Every rank of a group sees the same
+// thinnest slab, so all ranks resolve the same value.
 int effective_fuse(const sfl_context *c)
 {
     int f = c->opt_sor_fuse;
-    if (f == 0) f = (int64_t)min_owned_rows(c) * c->dim_x >= 24000000 ? 16 : 8;
+    if (f == 0) {
+        const int64_t cells = (int64_t)min_owned_rows(c) * c->dim_x;
+        f = cells >= 12000000 ? 16 : cells >= 6000000 ? 12 : 8;
+    }
     if (f < 2) f = 2;
     if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
     return f & ~1;

@@ -371,7 +371,7 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
         const long tiles = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                            g_end, rpc, true).n_tiles;
+                                            g_end, rpc, sor::kEdgeRowCost16).n_tiles;
         const double per_simd = (double)tiles / simds;
         const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
         const long rounds = (tiles + waves - 1) / waves;          // residency rounds
@@ -395,7 +395,7 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
                         : auto_rows_per_chunk<B>(g, g_begin, g_end, NS,
                                                  resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
     const sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                           g_end, rpc, true);
+                                           g_end, rpc, sor::kEdgeRowCost16);
     const int blocks = (t.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
     return hipGetLastError();

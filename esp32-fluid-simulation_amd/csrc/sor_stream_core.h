@@ -24,13 +24,14 @@
 //   O_m[r] = relax(O_{m-1}[r]; W/E from E_m[r];     S = E_m[r-1];     N = E_m[r+1];     d_O[r])
 // for version m = 1 .. NS/2 (version 0 = the loaded data).  Software pipeline: in the
 // iteration that receives input row y it computes E_m[y-(2m-1)] and O_m[y-2m] for every m, so
-// the finished row y-NS leaves the pipeline NS iterations after it entered.  Every value is
-// used for at most three iterations, hence three register slots per (colour, version),
-// addressed by (row mod 3).  The right-hand side d of a row is needed NS iterations long; it
-// waits in a per-lane ring of RING >= NS + 1 rows in LDS (nobody else reads it).  The loop body
-// is unrolled RING times, RING a multiple of 6 (= lcm of slot period 3 and row parity 2), so
-// that every register slot, row parity and ring slot is a compile-time constant: no address
-// arithmetic, no register moves.
+// the finished row y-NS leaves the pipeline NS iterations after it entered.  The last reader
+// of a version is the relaxation that produces the next one, so a row keeps ONE register per
+// colour for its whole stay and is updated in place (as the reference updates memory in place):
+// 2 * RING registers, addressed by (row mod RING).  The right-hand side d of a row is needed
+// NS iterations long; it waits in a per-lane ring of RING >= NS + 1 rows in LDS (nobody else
+// reads it), same index.  The loop body is unrolled RING times, RING a multiple of 6 (row parity
+// 2, prefetch depths 2 / 3 / 6), so that every register, row parity and ring slot is a
+// compile-time constant: no address arithmetic, no register moves.
 //
 // Validity: a tile is loaded with NS extra columns / rows on every side; pass s of the NS
 // spoils one more ring of cells, the tile's interior [NS from each loaded edge] is exact.
@@ -52,7 +53,6 @@ namespace sfl {
 namespace sor {
 
 
-constexpr int wrap3(int x) { return ((x % 3) + 3) % 3; }
 constexpr int wrapn(int x, int n) { return ((x % n) + n) % n; }
 constexpr bool is_even(int x) { return ((x % 2) + 2) % 2 == 0; }
 // rows of d alive at once (NS + 1), rounded up to a multiple of 6; also the unroll factor
@@ -79,11 +79,14 @@ struct Consts {
 };
 
 // B::kPrefetch = rows in flight ahead of the pipeline (must divide 6, hence every RING)
+// E[k] / O[k] hold the two colours of the row whose index is k modulo RING -- the NEWEST version
+// of that row computed so far: a relaxation overwrites its own input (the previous version's last
+// reader is the relaxation that replaces it, see iterate()), exactly as SOR does in memory.
 template <class B, int NS>
 struct Pipe {
     using V = typename B::V;
-    V E[NS / 2 + 1][3];
-    V O[NS / 2 + 1][3];             // O[NS/2] is never stored (written straight to memory)
+    V E[ring_rows(NS)];
+    V O[ring_rows(NS)];
     V pa[B::kPrefetch], pb[B::kPrefetch];  // prefetched p rows (cell a / cell b)
     V da[B::kPrefetch], db[B::kPrefetch];  // prefetched d rows
 };
@@ -140,10 +143,17 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             b = bk.select(bk.mask_and(ecb.in, rf.in_dom), b, bk.splat(-0.0f));
         }
         constexpr bool ev = is_even(U);
-        pp.E[0][wrap3(U)] = ev ? a : b;
-        pp.O[0][wrap3(U)] = ev ? b : a;
+        pp.E[U] = ev ? a : b;  // replaces row y - RING, which left the pipeline RING - NS rows ago
+        pp.O[U] = ev ? b : a;
     }
 
+    // Versions at this point, for stage m (E part: row r = y - 2m + 1, O part: row r = y - 2m):
+    //   O[r + 1] was brought to version m - 1 by stage m - 1 of THIS iteration, O[r] by the
+    //   previous iteration, O[r - 1] two iterations ago; none has reached version m yet (O_m of
+    //   row y - 2m is computed below, after E_m).  Likewise E[r + 1] = E_m (just computed),
+    //   E[r] = E_m (previous iteration), E[r - 1] = E_m (stage m + 1 comes later).  So every
+    //   relaxation reads exactly the versions the reference's in-place sweep reads
+    //   (poisson.cpp:14-61), and may overwrite its own input register.
 #pragma unroll
     for (int m = 1; m <= NS / 2; ++m) {
         // ---- E_m of row y - (2m - 1) ----
@@ -151,34 +161,32 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const int lag = 2 * m - 1;
             const int r = y - lag;
             const int rel = U - lag;                 // compile time after unrolling
-            const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
+            const int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
             const bool ev = is_even(rel);            // E cell is `a` in even rows
-            const V own = pp.E[m - 1][s0];
-            const V oc = pp.O[m - 1][s0];
+            const V own = pp.E[i0];
+            const V oc = pp.O[i0];
             const V w = ev ? bk.from_lower_lane(oc) : oc;
             const V e = ev ? oc : bk.from_upper_lane(oc);
-            const V d = bk.ring_load(wrapn(rel, RING), 0);
+            const V d = bk.ring_load(i0, 0);
             const RowFacts rf = bk.row_facts(r);
-            pp.E[m][s0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[m - 1][sm], pp.O[m - 1][sp],
-                                               d, ev ? eca : ecb, rf);
+            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[im], pp.O[ip], d, ev ? eca : ecb, rf);
         }
         // ---- O_m of row y - 2m ----
         {
             const int lag = 2 * m;
             const int r = y - lag;
             const int rel = U - lag;
-            const int s0 = wrap3(rel), sm = wrap3(rel - 1), sp = wrap3(rel + 1);
+            const int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
             const bool ev = is_even(rel);            // O cell is `b` in even rows
-            const V own = pp.O[m - 1][s0];
-            const V oc = pp.E[m][s0];
+            const V own = pp.O[i0];
+            const V oc = pp.E[i0];
             const V w = ev ? oc : bk.from_lower_lane(oc);
             const V e = ev ? bk.from_upper_lane(oc) : oc;
-            const V d = bk.ring_load(wrapn(rel, RING), 1);
+            const V d = bk.ring_load(i0, 1);
             const RowFacts rf = bk.row_facts(r);
-            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[m][sm], pp.E[m][sp], d,
-                                              ev ? ecb : eca, rf);
+            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[im], pp.E[ip], d, ev ? ecb : eca, rf);
             if (m < NS / 2) {
-                pp.O[m][s0] = res;
+                pp.O[i0] = res;
             } else if (r >= out_begin && r < out_end) {  // finished row leaves the pipeline
                 if (ev)
                     bk.store_row(r, oc, res);
@@ -273,16 +281,20 @@ SFL_HD int strip_step(const Tiling &t) { return t.tile_cols - 2 * t.halo_cols; }
 // column of lane 0's first cell for a strip (may be negative: columns left of the domain)
 SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t) - t.halo_cols; }
 
-// rows given to a boundary tile when interior tiles get `rows_per_chunk`
-SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns)
+// rows given to a boundary tile when interior tiles get `rows_per_chunk`; `sixteenths` / 16 is
+// the cost of an interior row relative to a boundary row.  Below kMinEdgeRows the warm-up rows
+// dominate a tile and shortening cannot equalise anything (measured: 1024^2 loses 30 % to the
+// extra tiles), so such launches keep the uniform tiling.
+constexpr int kEdgeRowCost16 = 10;
+constexpr int kMinEdgeRows = 8;
+SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 {
-    const int r = (rows_per_chunk + 2 * ns) * 5 / 8 - 2 * ns;
-    return r < 8 ? 8 : r;
+    return (rows_per_chunk + 2 * ns) * sixteenths / 16 - 2 * ns;
 }
 
-// `balance` = false: every tile gets rows_per_chunk rows.
+// `balance16` = 0: every tile gets rows_per_chunk rows; otherwise pass kEdgeRowCost16.
 SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin,
-                          int g_end, int rows_per_chunk, bool balance)
+                          int g_end, int rows_per_chunk, int balance16)
 {
     Tiling t;
     const int rows = g_end - g_begin;
@@ -302,9 +314,9 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
 
     t.rows_edge = rows_per_chunk;
     t.rows_first = t.rows_last = 0;
-    if (balance) {
-        const int re = balanced_edge_rows(rows_per_chunk, ns);
-        if (re < rows_per_chunk) {
+    if (balance16 > 0) {
+        const int re = balanced_edge_rows(rows_per_chunk, ns, balance16);
+        if (re >= kMinEdgeRows && re < rows_per_chunk) {
             t.rows_edge = re;
             // short first / last chunk of the inner strips, long enough that the next chunk is
             // clear of the boundary (see tile_touches_boundary)

@@ -168,7 +168,8 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
                bool vec2, bool poison, bool force_edge, bool balance)
 {
     using namespace sfl::sor;
-    const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk, balance);
+    const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
+                                 balance ? kEdgeRowCost16 : 0);
     {
         for (int tile = 0; tile < t.n_tiles; ++tile) {
             const TileRect rect = tile_rect(t, tile);
@@ -233,7 +234,8 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 }
 
 // Tiling property check: adds 1 to cover[row * dim_x + col] for every cell a tile of the launch
-// would store (its exact columns x its output rows) and returns the number of tiles; *n_edge
+// would store (its exact columns x its output rows; balance = 0 or the boundary row cost in
+// sixteenths) and returns the number of tiles; *n_edge
 // receives how many of them take the EDGE path.  A correct tiling leaves exactly 1 on every cell
 // of rows [g_begin, g_end) and 0 elsewhere.
 extern "C" __attribute__((visibility("default"))) int
@@ -242,7 +244,7 @@ emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, in
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance != 0);
+                                 balance);
     *n_edge = 0;
     for (int tile = 0; tile < t.n_tiles; ++tile) {
         const TileRect r = tile_rect(t, tile);

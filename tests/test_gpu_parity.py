@@ -433,6 +433,30 @@ def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks)
     assert info["exchanges"] == (1 if nranks == 2 else 2)   # rhs once (+ one p exchange at halo 32)
 
 
+@pytest.mark.parametrize("dim_y,fuse", [(1600, 12), (3200, 16)])
+def test_virtual_slabs_auto_fuse_depths_at_bench_width(sfl, oracle, dim_y, fuse):
+    """8192-wide slabs big enough for the deeper auto fuse depths (12 from 6 M cells per slab, 16
+    from 12 M): two virtual ranks, everything on auto, against the oracle."""
+    dim_x, iters, nranks = 8192, 20, 2
+    rng = np.random.default_rng(dim_y)
+    d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[0].last_solve_info()
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert_bit_equal(got, want, f"8192 x {dim_y} in 2 slabs, auto settings")
+    assert info["fuse"] == fuse and info["launches"] == -(-2 * iters // fuse)
+
+
 @pytest.mark.parametrize("dim_x,dim_y", [(61, 81), (2, 2), (40, 7), (257, 130)])
 def test_sketch_initial_condition_matches_oracle(sfl, oracle, dim_x, dim_y):
     """setup() (ino:196-241) on the GPU -- sectors by atan2f, then the two in-place

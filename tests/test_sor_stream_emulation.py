@@ -120,7 +120,7 @@ def test_tilings_partition_the_row_range(emu):
     for ns, dim_x, gdim_y, g_begin, g_end, rpc in cases:
         for tile_cols, align in ((128, 2), (256, 4)):
             counts = {}
-            for balance in (0, 1):
+            for balance in (0, 10, 7, 13):
                 cover = np.zeros((gdim_y, dim_x), np.int32)
                 n_edge = C.c_int(0)
                 n = emu.lib.emu_tiling_cover(ns, tile_cols, align, dim_x, gdim_y, g_begin, g_end, rpc, balance,
@@ -130,4 +130,4 @@ def test_tilings_partition_the_row_range(emu):
                 assert (cover[g_begin:g_end] == 1).all(), tag
                 assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
                 counts[balance] = n
-            assert counts[1] >= counts[0]
+            assert counts[10] >= counts[0]
