@@ -355,9 +355,9 @@ inline int device_simds()
 }
 
 // Output rows per interior wave tile (boundary tiles get fewer: sor::make_tiling).  Every tile
-// costs about the same (rows streamed = rpc + 2 NS of warm-up), a SIMD works through its tiles
-// essentially one VALU stream at a time, so a launch takes about ceil(tiles / SIMDs) * (rpc + 2 NS)
-// row-steps -- provided each SIMD holds ~2+ waves to cover DS / memory latency (measured on
+// costs about the same (rpc + 2 NS rows streamed, of which the prologue trips skip ~NS rows' worth
+// of passes), a SIMD works through its tiles essentially one VALU stream at a time, so a launch
+// takes about ceil(tiles / SIMDs) * (rpc + NS) row-steps -- provided each SIMD holds ~2+ waves to cover DS / memory latency (measured on
 // 8192 x {1024, 8192}, profiles/r01_rows_per_chunk.txt: fewer than ~2 waves per SIMD costs 1.4x,
 // 2..3 waves ~1.08x).  Pick the chunk count that minimises that, never exceeding the
 // resident-wave capacity by less than a full round.
@@ -370,13 +370,14 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
     const int max_chunks = (rows + 7) / 8;
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
-        const long tiles = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                            g_end, rpc, sor::kEdgeRowCost16).n_tiles;
+        const sor::Tiling t = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
+                                               g_end, rpc, sor::kEdgeRowCost16);
+        const long tiles = t.n_tiles;
         const double per_simd = (double)tiles / simds;
         const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
         const long rounds = (tiles + waves - 1) / waves;          // residency rounds
         const double penalty = per_simd >= 2.8 ? 1.0 : per_simd >= 1.9 ? 1.08 : 1.45;
-        double cost = (double)(serial > rounds ? serial : rounds) * (rpc + 2 * ns + 2) * penalty;
+        double cost = (double)(serial > rounds ? serial : rounds) * (rpc + ns + 2) * penalty;
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best_rows = rpc;

@@ -43,6 +43,10 @@
 #pragma once
 #include <utility>
 
+#ifndef SFL_EDGE_PROLOGUE_MAX_NS
+#define SFL_EDGE_PROLOGUE_MAX_NS 12
+#endif
+
 #if defined(__HIPCC__)
 #define SFL_HD __host__ __device__ __forceinline__
 #else
@@ -115,9 +119,26 @@ SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, t
     return out;
 }
 
+// Trips of a tile: the first ones are the pipeline's prologue.  Pass s (1 .. NS) only has to be
+// exact on rows [out_begin - (NS - s), ...), and it works on row y - s while row y enters, so in
+// the tile's J-th iteration (J = 0 for the first input row, out_begin - NS) pass s is needed
+// only if J >= 2 s: the prologue trips leave the others out (a quarter of the work of a 26-row
+// tile at NS = 12).  Leaving a pass out keeps an older version in the row's register; by the
+// same inequality nothing that is needed ever reads it.  The tile may start one row earlier
+// (even alignment), which only makes J an over-estimate.
+constexpr int kSteadyTrip = 2;  // TRIP = 0, 1: prologue trips; kSteadyTrip: every pass runs
+constexpr bool pass_runs(int trip, int ring, int u, int s)
+{
+    return trip >= kSteadyTrip || trip * ring + u >= 2 * s;
+}
+// The boundary path gets prologue trips only at the shallower fuse depths: at NS >= 14 they push
+// the kernel past 168 VGPRs (3 -> 2 waves per SIMD).
+constexpr bool edge_prologue(int ns) { return ns <= SFL_EDGE_PROLOGUE_MAX_NS; }
+constexpr int prologue_trips(int ns) { return (2 * ns + ring_rows(ns) - 1) / ring_rows(ns); }
+
 // The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int U>
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, int U>
 SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                     const EdgeCell<B> &ecb, int y, int out_begin, int out_end)
 {
@@ -157,7 +178,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
 #pragma unroll
     for (int m = 1; m <= NS / 2; ++m) {
         // ---- E_m of row y - (2m - 1) ----
-        {
+        if (pass_runs(TRIP, RING, U, 2 * m - 1)) {
             const int lag = 2 * m - 1;
             const int r = y - lag;
             const int rel = U - lag;                 // compile time after unrolling
@@ -172,7 +193,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[im], pp.O[ip], d, ev ? eca : ecb, rf);
         }
         // ---- O_m of row y - 2m ----
-        {
+        if (pass_runs(TRIP, RING, U, 2 * m)) {
             const int lag = 2 * m;
             const int r = y - lag;
             const int rel = U - lag;
@@ -202,14 +223,14 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
 // loads in flight and drains them all -- s_waitcnt vmcnt(0) -- once per trip); only the last,
 // partial trip of a tile checks after every iteration whether the remaining rows still need to
 // enter.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, bool PARTIAL, int... Us>
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool PARTIAL, int... Us>
 SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                          const EdgeCell<B> &ecb, int y, int out_begin, int out_end,
                          std::integer_sequence<int, Us...>)
 {
     const int y_stop = out_end + NS;
     (void)(((!PARTIAL || y + Us < y_stop) &&
-            (iterate<B, NS, EDGE, DX1, ZERO_IN, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end),
+            (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end),
              true)) && ...);
 }
 
@@ -234,12 +255,22 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 #pragma unroll
     for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
 
+    constexpr auto us = std::make_integer_sequence<int, RING>{};
+    if ((!EDGE || edge_prologue(NS)) && y + RING <= y_stop) {  // prologue trips: passes join one by one
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 0, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
+        y += RING;
+        if (prologue_trips(NS) >= 2 && y + RING <= y_stop) {
+            run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
+            y += RING;
+        }
+    }
+    static_assert(prologue_trips(NS) <= kSteadyTrip, "prologue trips");
     for (; y + RING <= y_stop; y += RING)
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, false>(bk, pp, c, eca, ecb, y, out_begin, out_end,
-                                                       std::make_integer_sequence<int, RING>{});
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, false>(bk, pp, c, eca, ecb, y, out_begin,
+                                                                    out_end, us);
     if (y < y_stop)
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, true>(bk, pp, c, eca, ecb, y, out_begin, out_end,
-                                                      std::make_integer_sequence<int, RING>{});
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, true>(bk, pp, c, eca, ecb, y, out_begin,
+                                                                   out_end, us);
 }
 
 // ---- tiling arithmetic shared by the launcher, the kernel and the emulator -----------------
@@ -251,7 +282,8 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 // Tiles that touch the domain boundary run the EDGE path, which costs about 1.6x the
 // instructions of the interior path per row.  All tiles of a launch are resident at once, so the
 // launch lasts as long as its slowest wave: boundary tiles are therefore given fewer rows
-// (`rows_edge`, chosen so that (rows_edge + 2 NS) * 1.6 ~ rows_per_chunk + 2 NS).  Boundary
+// (`rows_edge`, chosen so that (rows_edge + 2 NS) * 1.6 ~ rows_per_chunk + NS: the boundary path has
+// no prologue trips, they would cost it a wave of occupancy).  Boundary
 // tiles are: every tile of a boundary strip (strip 0 and the strips whose columns reach
 // dim_x), and the first / last chunk of the other ("inner") strips when the row range reaches
 // the bottom / top of the domain.  Measured on 8192^2, NS = 16: 261 -> 2xx us per launch.
@@ -282,14 +314,20 @@ SFL_HD int strip_step(const Tiling &t) { return t.tile_cols - 2 * t.halo_cols; }
 SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t) - t.halo_cols; }
 
 // rows given to a boundary tile when interior tiles get `rows_per_chunk`; `sixteenths` / 16 is
-// the cost of an interior row relative to a boundary row.  Below kMinEdgeRows the warm-up rows
-// dominate a tile and shortening cannot equalise anything (measured: 1024^2 loses 30 % to the
-// extra tiles), so such launches keep the uniform tiling.
+// the cost of an interior row relative to a boundary row.  A tile costs about rows + NS
+// row-steps with prologue trips and rows + 2 NS without.  Boundary tiles are never shorter than
+// kMinEdgeRows; when even such a tile would outlast the interior ones by more than a fifth,
+// shortening cannot equalise anything (small grids: the warm-up rows dominate and the extra tiles
+// only cost parallelism, measured 1024^2: -30 %) and 0 is returned: keep the uniform tiling.
 constexpr int kEdgeRowCost16 = 10;
 constexpr int kMinEdgeRows = 8;
 SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 {
-    return (rows_per_chunk + 2 * ns) * sixteenths / 16 - 2 * ns;
+    const int warm = edge_prologue(ns) ? ns : 2 * ns;
+    const int r = (rows_per_chunk + ns) * sixteenths / 16 - warm;
+    if (r >= kMinEdgeRows) return r;
+    // cost of a minimum-height boundary tile against an interior tile, in interior row-steps
+    return (kMinEdgeRows + warm) * 16 * 5 <= (rows_per_chunk + ns) * sixteenths * 6 ? kMinEdgeRows : 0;
 }
 
 // `balance16` = 0: every tile gets rows_per_chunk rows; otherwise pass kEdgeRowCost16.
@@ -316,7 +354,7 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
     t.rows_first = t.rows_last = 0;
     if (balance16 > 0) {
         const int re = balanced_edge_rows(rows_per_chunk, ns, balance16);
-        if (re >= kMinEdgeRows && re < rows_per_chunk) {
+        if (re > 0 && re < rows_per_chunk) {
             t.rows_edge = re;
             // short first / last chunk of the inner strips, long enough that the next chunk is
             // clear of the boundary (see tile_touches_boundary)
