@@ -78,6 +78,7 @@ SIGNATURES = {
     "sfl_host_calculate_divergence": (_i, [_pf, _pf, _i, _i, _f]),
     "sfl_host_subtract_gradient": (_i, [_pf, _pf, _i, _i, _f]),
     "sfl_host_poisson_solve": (_i, [_pf, _pf, _i, _i, _f, _i, _f]),
+    "sfl_host_release": (_i, []),
     "sfl_create": (_i, [C.POINTER(_ctx), _i, _i, _i]),
     "sfl_create_slab": (_i, [C.POINTER(_ctx), _i, _i, _i, _i, _i]),
     "sfl_destroy": (_i, [_ctx]),

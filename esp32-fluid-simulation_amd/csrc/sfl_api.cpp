@@ -360,10 +360,57 @@ int default_device()
     return e ? atoi(e) : 0;
 }
 
-// RAII helper for the host-pointer drop-ins
-struct TempCtx {
+// Context of a host-pointer drop-in call.  The sketch's loop() calls five operators per frame
+// on a 61 x 81 grid (ino:252-287): creating stream, events and buffers anew for each of them cost
+// 3.2 ms per frame (profiles/r01_host_dropin_pcie.txt), ten times the reference's CPU time.  So
+// the context of the last call stays with the calling thread -- for grids of up to
+// kHostCacheCells cells only (<= 140 MB of fields; above that the set-up is noise next to the PCIe
+// transfers and nothing is retained) -- until the shape changes, a call fails, or
+// sfl_host_release() is called.
+constexpr int64_t kHostCacheCells = 1 << 22;
+thread_local sfl_context *g_host_cached = nullptr;
+
+struct HostCtx {
     sfl_context *c = nullptr;
-    ~TempCtx() { if (c) sfl_destroy(c); }
+    bool cached = false, ok = false;
+
+    int acquire(int dim_x, int dim_y)
+    {
+        const int dev = default_device();
+        sfl_context *k = g_host_cached;
+        if (k && k->device == dev && k->dim_x == dim_x && k->gdim_y == dim_y) {
+            c = k;
+            cached = true;
+            sfl_context fresh;  // option defaults
+            c->opt_sor_kernel = fresh.opt_sor_kernel;
+            c->opt_sor_fuse = fresh.opt_sor_fuse;
+            c->opt_sor_rows = fresh.opt_sor_rows;
+            c->opt_sor_lane_cells = fresh.opt_sor_lane_cells;
+            return SFL_OK;
+        }
+        if (k) {
+            g_host_cached = nullptr;
+            sfl_destroy(k);
+        }
+        SFL_TRY(sfl_create(&c, dev, dim_x, dim_y));
+        if ((int64_t)dim_x * dim_y <= kHostCacheCells) {
+            g_host_cached = c;
+            cached = true;
+        }
+        return SFL_OK;
+    }
+    int done(int rc)
+    {
+        ok = rc == SFL_OK;
+        return rc;
+    }
+    ~HostCtx()
+    {
+        if (!c) return;
+        if (cached && ok) return;
+        if (cached) g_host_cached = nullptr;  // unknown state after a failure: start afresh
+        sfl_destroy(c);
+    }
 };
 
 int upload_raw(sfl_context *c, void *dev, const void *host, size_t elem_bytes)
@@ -934,8 +981,8 @@ int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int d
 {
     if (!next_p || !p || !vel) return fail(SFL_ERR_INVALID, "NULL field pointer");
     if (next_p == p) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
-    TempCtx t;
-    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
     sfl_context *c = t.c;
     SFL_TRY(ensure(c, c->vel, 8, false));
     SFL_TRY(ensure(c, c->vel_tmp, 8, false));
@@ -952,7 +999,7 @@ int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int d
     int rc = e == hipSuccess ? download_raw(c, c->vel_tmp, next_p, 8)
                              : fail(SFL_ERR_HIP, "advect launch failed: %s", hipGetErrorString(e));
     if (other) (void)hipFree(other);
-    return rc;
+    return t.done(rc);
 }
 
 int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *vel, int dim_x,
@@ -960,41 +1007,41 @@ int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *v
 {
     if (!next_p || !p || !vel) return fail(SFL_ERR_INVALID, "NULL field pointer");
     if (next_p == p) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
-    TempCtx t;
-    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, vel, (size_t)dim_x * dim_y * 8));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_COLOR, p, (size_t)dim_x * dim_y * 12));
     SFL_TRY(sfl_advect_color(t.c, dt, no_slip));
-    return sfl_download(t.c, SFL_FIELD_COLOR, next_p, (size_t)dim_x * dim_y * 12);
+    return t.done(sfl_download(t.c, SFL_FIELD_COLOR, next_p, (size_t)dim_x * dim_y * 12));
 }
 
 int sfl_host_calculate_divergence(float *div, const float *v, int dim_x, int dim_y, float dx)
 {
     if (!div || !v) return fail(SFL_ERR_INVALID, "NULL field pointer");
-    TempCtx t;
-    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8));
     SFL_TRY(sfl_calculate_divergence(t.c, dx));
-    return sfl_download(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4);
+    return t.done(sfl_download(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4));
 }
 
 int sfl_host_subtract_gradient(float *v, const float *p, int dim_x, int dim_y, float dx)
 {
     if (!v || !p) return fail(SFL_ERR_INVALID, "NULL field pointer");
-    TempCtx t;
-    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4));
     SFL_TRY(sfl_subtract_gradient(t.c, dx));
-    return sfl_download(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8);
+    return t.done(sfl_download(t.c, SFL_FIELD_VELOCITY, v, (size_t)dim_x * dim_y * 8));
 }
 
 int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, float dx, int iters,
                            float omega)
 {
     if (!p || !div) return fail(SFL_ERR_INVALID, "NULL field pointer");
-    TempCtx t;
-    SFL_TRY(sfl_create(&t.c, default_device(), dim_x, dim_y));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
     const char *k = getenv("SFL_SOR_KERNEL");
     if (k) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_KERNEL, atoi(k)));
     const char *f = getenv("SFL_SOR_FUSE");
@@ -1003,7 +1050,14 @@ int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, flo
     if (l) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_LANE_CELLS, atoi(l)));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4));
     SFL_TRY(sfl_poisson_solve(t.c, dx, iters, omega));
-    return sfl_download(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4);
+    return t.done(sfl_download(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4));
+}
+
+int sfl_host_release(void)
+{
+    sfl_context *k = g_host_cached;
+    g_host_cached = nullptr;
+    return k ? sfl_destroy(k) : SFL_OK;
 }
 
 }  // extern "C"

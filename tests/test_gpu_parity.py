@@ -483,3 +483,31 @@ def test_headline_size_full_step_vs_oracle(hip, oracle):
     want = oracle.step(v, c, DT, 1.0, 2, OMEGA)
     for name, a, b in zip(("v", "div", "p", "colour"), got, want):
         assert_bit_equal(a, b, f"8192^2 step: {name}")
+
+
+def test_host_dropins_keep_a_working_context_per_thread(sfl, oracle):
+    """The host-pointer drop-ins reuse their device-side context between calls (same thread, same
+    grid shape), replace it when the shape changes and free it on sfl_host_release(); results are
+    those of independent calls."""
+    import ctypes as C
+    lib = sfl.capi.lib()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rng = np.random.default_rng(12)
+    for dim_x, dim_y in [(61, 81), (61, 81), (40, 7), (61, 81), (130, 33)]:
+        v = (rng.standard_normal((dim_y, dim_x, 2)) * 2).astype(np.float32)
+        d = np.empty((dim_y, dim_x), np.float32)
+        p = np.empty((dim_y, dim_x), np.float32)
+        assert lib.sfl_host_calculate_divergence(fp(d), fp(v), dim_x, dim_y, C.c_float(1.0)) == 0
+        assert_bit_equal(d, oracle.divergence(v, 1.0), f"divergence {dim_x}x{dim_y}")
+        for iters in (3, 7):   # a second solve on the reused context starts from zero again
+            assert lib.sfl_host_poisson_solve(fp(p), fp(d), dim_x, dim_y, C.c_float(1.0), iters,
+                                              C.c_float(1.96)) == 0
+            assert_bit_equal(p, oracle.poisson_solve(d, 1.0, iters, OMEGA), f"solve {dim_x}x{dim_y} x{iters}")
+        got = v.copy()
+        assert lib.sfl_host_subtract_gradient(fp(got), fp(p), dim_x, dim_y, C.c_float(1.0)) == 0
+        assert_bit_equal(got, oracle.subtract_gradient(v, p, 1.0), f"gradient {dim_x}x{dim_y}")
+    assert lib.sfl_host_release() == 0
+    assert lib.sfl_host_release() == 0   # nothing left: still fine
+    assert lib.sfl_host_calculate_divergence(fp(d), fp(v), dim_x, dim_y, C.c_float(1.0)) == 0
+    assert_bit_equal(d, oracle.divergence(v, 1.0), "after release")
+    assert lib.sfl_host_release() == 0
