@@ -135,10 +135,15 @@ constexpr bool pass_runs(int trip, int ring, int u, int s)
 // the kernel past 168 VGPRs (3 -> 2 waves per SIMD).
 constexpr bool edge_prologue(int ns) { return ns <= SFL_EDGE_PROLOGUE_MAX_NS; }
 constexpr int prologue_trips(int ns) { return (2 * ns + ring_rows(ns) - 1) / ring_rows(ns); }
+// After the prologue trips the leaving row y - NS is at or above out_begin (the tile starts at
+// out_begin - NS or one row lower), and a full trip never runs past out_end + NS: steady full
+// trips can store without looking.  (A conditional store costs a branch per row and, as
+// compiled, eight SGPR spill moves for its buffer descriptor.)
+constexpr bool steady_rows_are_output(int ns) { return prologue_trips(ns) * ring_rows(ns) >= 2 * ns + 1; }
 
 // The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, int U>
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool GUARD_STORE, int U>
 SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                     const EdgeCell<B> &ecb, int y, int out_begin, int out_end)
 {
@@ -208,7 +213,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[im], pp.E[ip], d, ev ? ecb : eca, rf);
             if (m < NS / 2) {
                 pp.O[i0] = res;
-            } else if (r >= out_begin && r < out_end) {  // finished row leaves the pipeline
+            } else if (!GUARD_STORE || (r >= out_begin && r < out_end)) {  // finished row leaves
                 if (ev)
                     bk.store_row(r, oc, res);
                 else
@@ -229,8 +234,12 @@ SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeC
                          std::integer_sequence<int, Us...>)
 {
     const int y_stop = out_end + NS;
+    // steady full trips run only after the prologue trips on the paths that have them
+    constexpr bool guard = PARTIAL || TRIP < kSteadyTrip || !steady_rows_are_output(NS) ||
+                           (EDGE && !edge_prologue(NS));
     (void)(((!PARTIAL || y + Us < y_stop) &&
-            (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, Us>(bk, pp, c, eca, ecb, y + Us, out_begin, out_end),
+            (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, guard, Us>(bk, pp, c, eca, ecb, y + Us, out_begin,
+                                                                 out_end),
              true)) && ...);
 }
 

@@ -53,6 +53,8 @@ struct EmuBackend {
     int out_lo, out_hi;
     bool vec2;    // emulate the 8-byte access variant (pair handled as a whole)
     bool poison_on;
+    int tile_r0, tile_r1;  // output rows of the tile being streamed
+    int *stray_stores;
     std::vector<float> ring;  // [slot][plane][lane]
 
     V splat(float x) const
@@ -124,6 +126,10 @@ struct EmuBackend {
     }
     void store_row(int r, const V &a, const V &b) const
     {
+        if (r < tile_r0 || r >= tile_r1) {  // a store outside the tile's output rows is a bug
+            ++*stray_stores;
+            return;
+        }
         for (int i = 0; i < 64; ++i) {
             const int xa = x0 + 2 * i;
             const bool a_in = xa >= 0 && xa < dim_x, b_in = xa + 1 >= 0 && xa + 1 < dim_x;
@@ -163,13 +169,14 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 }
 
 template <int NS>
-void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
+int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
                bool vec2, bool poison, bool force_edge, bool balance)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
                                  balance ? kEdgeRowCost16 : 0);
+    int stray = 0;
     {
         for (int tile = 0; tile < t.n_tiles; ++tile) {
             const TileRect rect = tile_rect(t, tile);
@@ -191,6 +198,9 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
             bk.ring.assign((size_t)ring_rows(NS) * 2 * 64,
                            poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
             const int r0 = rect.r0, r1 = rect.r1;
+            bk.tile_r0 = r0;
+            bk.tile_r1 = r1;
+            bk.stray_stores = &stray;
             Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
             const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
             const bool dx1 = dx == 1.0f;
@@ -207,6 +217,7 @@ void run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int g
 #undef EMU_RUN
         }
     }
+    return stray;
 }
 
 }  // namespace
@@ -222,9 +233,8 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
-        run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                     rows_per_chunk, vec2, poison, force_edge, balance);                           \
-        return 0;
+        return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx,    \
+                            omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)
