@@ -296,26 +296,34 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     const int x0 = sor::strip_x0(t, rect.strip);
     const int r0 = rect.r0, r1 = rect.r1;
 
-    B bk;
     const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
     const unsigned records = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
-    bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
-    bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
-    bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
-    bk.dim_x = g.dim_x;
-    bk.gdim_y = g.gdim_y;
-    bk.grow0 = g.grow0;
-    bk.row_lo = max(g.grow0, 0);
-    bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
-    bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
-
-    sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
-
+    // The backend (buffer resources, lane offsets) is built inside each branch: built once in
+    // front of the branch, its SGPRs live through the register-hungry boundary path too and the
+    // allocator parks the store's descriptor in spill lanes, reloading it for every row of the
+    // interior path as well (8 v_readlane / v_writelane per row, 6 % of its VALU-class instructions).
+    auto backend = [&]() {
+        B bk;
+        bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
+        bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
+        bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
+        bk.dim_x = g.dim_x;
+        bk.gdim_y = g.gdim_y;
+        bk.grow0 = g.grow0;
+        bk.row_lo = max(g.grow0, 0);
+        bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
+        bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
+        return bk;
+    };
     if (sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
+        B bk = backend();
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
     } else {
+        B bk = backend();
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
     }
