@@ -433,6 +433,30 @@ def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks)
     assert info["exchanges"] == (1 if nranks == 2 else 2)   # rhs once (+ one p exchange at halo 32)
 
 
+def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
+    """The program bench.py runs at --gpus 8 (8192^2 in eight 1024-row slabs, every option on auto:
+    fuse 12, halo 64, two supersteps at 40 iterations so that p is exchanged as well as the rhs),
+    executed by eight virtual ranks on one GPU, against the oracle."""
+    dim, iters, nranks = 8192, 40, 8
+    rng = np.random.default_rng(88)
+    d = (rng.standard_normal((dim, dim)) * 0.1).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim, dim, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[3].last_solve_info()
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert_bit_equal(got, want, "8192^2 in 8 slabs, auto settings")
+    assert info["fuse"] == 12 and info["launches"] == 7 and info["exchanges"] == 2
+
+
 @pytest.mark.parametrize("dim_y,fuse", [(1600, 12), (3200, 16)])
 def test_virtual_slabs_auto_fuse_depths_at_bench_width(sfl, oracle, dim_y, fuse):
     """8192-wide slabs big enough for the deeper auto fuse depths (12 from 6 M cells per slab, 16
