@@ -449,7 +449,7 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 }  // namespace
 
 // One non-template entry per fuse depth; the depths are spread over several translation units
-// (SFL_NS_GROUP = 0..3, see csrc/Makefile) so that they compile in parallel.
+// (SFL_NS_GROUP = 0..5, see csrc/Makefile) so that they compile in parallel.
 #ifndef SFL_NS_GROUP
 #define SFL_NS_GROUP (-1)  // single translation unit: everything
 #endif
@@ -470,12 +470,18 @@ SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
 SFL_DEFINE_NS(2) SFL_DEFINE_NS(4) SFL_DEFINE_NS(6)
 #endif
 #if SFL_NS_GROUP == 1 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS(8) SFL_DEFINE_NS(10)
+SFL_DEFINE_NS(8)
 #endif
 #if SFL_NS_GROUP == 2 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS(12) SFL_DEFINE_NS(14)
+SFL_DEFINE_NS(10)
 #endif
 #if SFL_NS_GROUP == 3 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(12)
+#endif
+#if SFL_NS_GROUP == 4 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS(14)
+#endif
+#if SFL_NS_GROUP == 5 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(16)
 #endif
 

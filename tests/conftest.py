@@ -27,7 +27,7 @@ def _ensure_built():
     import subprocess
     pkg = os.path.join(ROOT, "esp32-fluid-simulation_amd")
     jobs = [
-        (os.path.join(pkg, "lib", "libsfl_hip.so"), ["make", "-C", os.path.join(pkg, "csrc"), "-j4"]),
+        (os.path.join(pkg, "lib", "libsfl_hip.so"), ["make", "-C", os.path.join(pkg, "csrc"), "-j6"]),
         (os.path.join(pkg, "lib", "libsfl_dropin.so"), ["make", "-C", os.path.join(pkg, "host")]),
         (os.path.join(ROOT, "oracle", "libsf_oracle.so"), ["make", "-C", os.path.join(ROOT, "oracle")]),
         (os.path.join(ROOT, "tests", "cpp", "libsor_stream_emu.so"), ["make", "-C", os.path.join(ROOT, "tests", "cpp")]),
