@@ -30,7 +30,7 @@ def _ensure_built():
         (os.path.join(pkg, "lib", "libsfl_hip.so"), ["make", "-C", os.path.join(pkg, "csrc"), "-j6"]),
         (os.path.join(pkg, "lib", "libsfl_dropin.so"), ["make", "-C", os.path.join(pkg, "host")]),
         (os.path.join(ROOT, "oracle", "libsf_oracle.so"), ["make", "-C", os.path.join(ROOT, "oracle")]),
-        (os.path.join(ROOT, "tests", "cpp", "libsor_stream_emu.so"), ["make", "-C", os.path.join(ROOT, "tests", "cpp")]),
+        (os.path.join(ROOT, "tests", "cpp", "libsor_stream_emu.so"), ["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-j4"]),
     ]
     for artefact, cmd in jobs:
         if not os.path.exists(artefact):

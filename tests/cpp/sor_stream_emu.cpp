@@ -222,6 +222,37 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 
 }  // namespace
 
+// One non-template entry per fuse depth; the depths are spread over several objects
+// (-DEMU_NS_GROUP=0..3, see Makefile) because a single translation unit takes four minutes.
+#ifndef EMU_NS_GROUP
+#define EMU_NS_GROUP (-1)  // everything in one translation unit
+#endif
+#define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
+                 int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
+                 bool vec2, bool poison, bool force_edge, bool balance
+#define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
+#define EMU_DEFINE(N)                                                                             \
+    int emu_run_ns##N(EMU_ARGS)                                                                   \
+    {                                                                                             \
+        return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
+                            rows_per_chunk, vec2, poison, force_edge, balance);                   \
+    }
+EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
+EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
+#if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
+EMU_DEFINE(2) EMU_DEFINE(4) EMU_DEFINE(6) EMU_DEFINE(8)
+#endif
+#if EMU_NS_GROUP == 1 || EMU_NS_GROUP == -1
+EMU_DEFINE(10) EMU_DEFINE(12)
+#endif
+#if EMU_NS_GROUP == 2 || EMU_NS_GROUP == -1
+EMU_DEFINE(14)
+#endif
+#if EMU_NS_GROUP == 3 || EMU_NS_GROUP == -1
+EMU_DEFINE(16)
+#endif
+
+#if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
 //        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles)
 extern "C" __attribute__((visibility("default"))) int
@@ -233,8 +264,8 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
-        return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx,    \
-                            omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
+        return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
+                             omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)
@@ -268,3 +299,4 @@ emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, in
     }
     return t.n_tiles;
 }
+#endif  // EMU_NS_GROUP 0

@@ -20,7 +20,7 @@ def emu():
     d = os.path.join(ROOT, "tests", "cpp")
     so = os.path.join(d, "libsor_stream_emu.so")
     if not os.path.exists(so):
-        subprocess.run(["make", "-C", d], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", d, "-j4"], check=True, stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
     lib.emu_sor_fused.restype = C.c_int
