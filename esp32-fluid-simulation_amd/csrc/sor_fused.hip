@@ -14,12 +14,22 @@
 // add / mul round each component separately, exactly like the scalar instructions.
 #include "kernels.h"
 #include "sor_stream_core.h"
+#include "sor_stream_pairs.h"
 
 namespace sfl {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = 64 * kWavesPerBlock;
+
+// The stage-paired interior pipeline (sor_stream_pairs.h) is experimental: bit-exact on the CPU
+// emulator and on the GPU, but as compiled today not faster (profiles/r01_rows_per_chunk.txt), so it
+// is only built with -DSFL_EXPERIMENTAL_PAIRS and then only used when SFL_SOR_PAIRS=1 is set.
+#ifdef SFL_EXPERIMENTAL_PAIRS
+constexpr bool kBuildPairs = true;
+#else
+constexpr bool kBuildPairs = false;
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -37,6 +47,19 @@ __device__ __forceinline__ float lane_above(float x)  // value of lane + 1
 {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+
+// the same shifts with bound_ctrl (lanes without a source read 0): as a stand-alone v_mov_b32_dpp
+// this form needs no zero-initialised destination (sor_stream_pairs.h moves both halves of a pair)
+__device__ __forceinline__ __attribute__((unused)) float lane_below_bc(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ __attribute__((unused)) float lane_above_bc(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true));
 }
 
 // State shared by both flavours.  Loads are UNCONDITIONAL and branch-free: the row index is
@@ -72,10 +95,17 @@ template <int NS, bool VEC, bool ZERO_IN>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
+    using V2 = v2f;  // {row r, row r - KP} of one colour (sor_stream_pairs.h)
     static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6;
-    static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
+    // LDS per wave: the scalar ring (RING rows x 2 planes x 64 lanes x 4 B) or, at the depths that
+    // have the paired pipeline, its ring of 8-byte pairs
+    static constexpr int kRingFloats = kBuildPairs && sor::pairs_supported(NS)
+                                           ? (sor::pair_ring_rows(NS) * 4 > sor::ring_rows(NS) * 2
+                                                  ? sor::pair_ring_rows(NS) * 4 : sor::ring_rows(NS) * 2) * 64
+                                           : sor::ring_rows(NS) * 2 * 64;
 
     float *ring;         // this lane's word of ring slot 0 / plane 0 in LDS
+    int lane_id;
     int off_a, off_b;    // byte offsets of the clamped load columns of cell a / b
     int off_out;         // byte offset of the true column of cell a
     bool a_out, b_out;   // columns this tile is responsible for (exact interior, in the domain)
@@ -83,6 +113,7 @@ struct Lane2 : WaveCommon {
     __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
     {
         ring = ring_base + lane;
+        lane_id = lane;
         const int xa = x0 + 2 * lane;
         if (VEC) {  // dim_x even: the pair is inside or outside as a whole
             off_a = 4 * min(max(xa, 0), dim_x - 2);
@@ -120,6 +151,22 @@ struct Lane2 : WaveCommon {
         V r;
         asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
         return r;
+    }
+    // pairs of rows (sor_stream_pairs.h): arithmetic on V2 compiles to v_pk_add_f32 / v_pk_mul_f32
+    __device__ __forceinline__ V2 make2(V lo, V hi) const { return V2{lo, hi}; }
+    __device__ __forceinline__ V lo(V2 p) const { return p.x; }
+    __device__ __forceinline__ V hi(V2 p) const { return p.y; }
+    __device__ __forceinline__ V2 scale2(float s, V2 v) const { return s * v; }
+    __device__ __forceinline__ V2 from_lower_lane2(V2 p) const { return V2{lane_below_bc(p.x), lane_below_bc(p.y)}; }
+    __device__ __forceinline__ V2 from_upper_lane2(V2 p) const { return V2{lane_above_bc(p.x), lane_above_bc(p.y)}; }
+    // paired ring: [R slots][2 planes][64 lanes] of {d[r], d[r - KP]} (8-byte DS accesses); the
+    // lane's element of slot 0 / plane 0 sits at the same LDS address as the scalar ring's base
+    __device__ __forceinline__ V2 *ring2() const { return reinterpret_cast<V2 *>(ring - lane_id) + lane_id; }
+    __device__ __forceinline__ void ring_store2(int slot, int plane, V2 x) const { ring2()[(slot * 2 + plane) * 64] = x; }
+    __device__ __forceinline__ V2 ring_load_pair(int slot, int plane) const { return ring2()[(slot * 2 + plane) * 64]; }
+    __device__ __forceinline__ V ring_load_lo(int slot, int plane) const
+    {
+        return reinterpret_cast<const float *>(&ring2()[(slot * 2 + plane) * 64])[0];
     }
 
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
@@ -324,6 +371,12 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     } else {
         B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        if constexpr (kBuildPairs && B::kCells == 2 && sor::pairs_supported(NS)) {
+            if (t.pairs) {
+                sor::stream_tile_pairs<B, NS, DX1, ZERO_IN>(bk, prm.dx, prm.omega, prm.one_minus_omega, r0, r1);
+                return;
+            }
+        }
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
     }
@@ -403,8 +456,9 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
                         ? rows_per_chunk
                         : auto_rows_per_chunk<B>(g, g_begin, g_end, NS,
                                                  resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
-    const sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                           g_end, rpc, sor::kEdgeRowCost16);
+    sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
+                                     g_end, rpc, sor::kEdgeRowCost16);
+    t.pairs = kBuildPairs && getenv("SFL_SOR_PAIRS") ? atoi(getenv("SFL_SOR_PAIRS")) : 0;
     const int blocks = (t.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
     return hipGetLastError();

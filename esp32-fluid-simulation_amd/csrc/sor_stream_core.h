@@ -310,6 +310,7 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
+    int pairs;            // interior tiles run the stage-paired pipeline (sor_stream_pairs.h)
 };
 
 struct TileRect {
@@ -345,6 +346,7 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
 {
     Tiling t;
     const int rows = g_end - g_begin;
+    t.pairs = 0;
     t.ns = ns;
     t.dim_x = dim_x;
     t.g_begin = g_begin;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "sor_stream_core.h"
+#include "sor_stream_pairs.h"
 
 namespace {
 
@@ -40,9 +41,17 @@ EMU_BINOP(-)
 EMU_BINOP(*)
 #undef EMU_BINOP
 
+// a pair of rows (sor_stream_pairs.h): both halves 64 lanes wide
+struct V64x2 {
+    V64 x, y;
+};
+inline V64x2 operator+(const V64x2 &a, const V64x2 &b) { return {a.x + b.x, a.y + b.y}; }
+inline V64x2 operator-(const V64x2 &a, const V64x2 &b) { return {a.x - b.x, a.y - b.y}; }
+
 struct EmuBackend {
     using V = V64;
     using M = M64;
+    using V2 = V64x2;
     static constexpr int kPrefetch = 6;
 
     const float *p_in;
@@ -151,6 +160,39 @@ struct EmuBackend {
         return r;
     }
     V detach(const V &x) const { return x; }
+    V2 make2(const V &lo, const V &hi) const { return {lo, hi}; }
+    V lo(const V2 &p) const { return p.x; }
+    V hi(const V2 &p) const { return p.y; }
+    V2 scale2(float s, const V2 &v) const
+    {
+        V2 r;
+        for (int i = 0; i < 64; ++i) {
+            r.x.l[i] = s * v.x.l[i];
+            r.y.l[i] = s * v.y.l[i];
+        }
+        return r;
+    }
+    V2 from_lower_lane2(const V2 &p) const { return {from_lower_lane(p.x), from_lower_lane(p.y)}; }
+    V2 from_upper_lane2(const V2 &p) const { return {from_upper_lane(p.x), from_upper_lane(p.y)}; }
+    // paired ring (sor_stream_pairs.h): [slot][plane][half][lane], sharing the scalar ring's storage
+    void ring_store2(int slot, int plane, const V2 &x)
+    {
+        std::memcpy(&ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], x.x.l, sizeof(x.x.l));
+        std::memcpy(&ring[(size_t)((slot * 2 + plane) * 2 + 1) * 64], x.y.l, sizeof(x.y.l));
+    }
+    V2 ring_load_pair(int slot, int plane) const
+    {
+        V2 r;
+        std::memcpy(r.x.l, &ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], sizeof(r.x.l));
+        std::memcpy(r.y.l, &ring[(size_t)((slot * 2 + plane) * 2 + 1) * 64], sizeof(r.y.l));
+        return r;
+    }
+    V ring_load_lo(int slot, int plane) const
+    {
+        V r;
+        std::memcpy(r.l, &ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], sizeof(r.l));
+        return r;
+    }
 };
 
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
@@ -171,7 +213,7 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge, bool balance)
+               bool vec2, bool poison, bool force_edge, bool balance, bool pairs)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
@@ -195,7 +237,8 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.out_hi = bk.x0 + t.tile_cols - t.halo_cols;
             bk.vec2 = vec2;
             bk.poison_on = poison;
-            bk.ring.assign((size_t)ring_rows(NS) * 2 * 64,
+            bk.ring.assign((size_t)(pairs_supported(NS) && pair_ring_rows(NS) * 2 > ring_rows(NS)
+                                        ? pair_ring_rows(NS) * 2 : ring_rows(NS)) * 2 * 64,
                            poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
             const int r0 = rect.r0, r1 = rect.r1;
             bk.tile_r0 = r0;
@@ -207,6 +250,14 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
 #define EMU_RUN(EDGE, DX1, ZERO) stream_tile<EmuBackend, NS, EDGE, DX1, ZERO>(bk, c, eca, ecb, r0, r1)
+#define EMU_RUN_PAIRS(DX1, ZERO) stream_tile_pairs<EmuBackend, NS, DX1, ZERO>(bk, dx, omega, 1.0f - omega, r0, r1)
+            if constexpr (pairs_supported(NS)) {
+                if (pairs && !edge) {  // interior tiles: the stage-paired pipeline
+                    if (dx1) { if (zero_in) EMU_RUN_PAIRS(true, true); else EMU_RUN_PAIRS(true, false); }
+                    else     { if (zero_in) EMU_RUN_PAIRS(false, true); else EMU_RUN_PAIRS(false, false); }
+                    continue;
+                }
+            }
             if (edge) {
                 if (dx1) { if (zero_in) EMU_RUN(true, true, true); else EMU_RUN(true, true, false); }
                 else     { if (zero_in) EMU_RUN(true, false, true); else EMU_RUN(true, false, false); }
@@ -215,6 +266,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
                 else     { if (zero_in) EMU_RUN(false, false, true); else EMU_RUN(false, false, false); }
             }
 #undef EMU_RUN
+#undef EMU_RUN_PAIRS
         }
     }
     return stray;
@@ -229,13 +281,13 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
-                 bool vec2, bool poison, bool force_edge, bool balance
+                 bool vec2, bool poison, bool force_edge, bool balance, bool pairs
 #define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
 #define EMU_DEFINE(N)                                                                             \
     int emu_run_ns##N(EMU_ARGS)                                                                   \
     {                                                                                             \
         return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                            rows_per_chunk, vec2, poison, force_edge, balance);                   \
+                            rows_per_chunk, vec2, poison, force_edge, balance, pairs);            \
     }
 EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
 EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
@@ -254,18 +306,20 @@ EMU_DEFINE(16)
 
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
-//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles)
+//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
+//        bit4 = interior tiles run the stage-paired pipeline (sor_stream_pairs.h)
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
               int lrows, int g_begin, int g_end, int ns, float dx, float omega,
               int rows_per_chunk, int flags)
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
+    const bool pairs = flags & 16;
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
         return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
-                             omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
+                             omega, rows_per_chunk, vec2, poison, force_edge, balance, pairs) ? -3 : 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)

@@ -29,13 +29,13 @@ def emu():
     lib.emu_tiling_cover.restype = C.c_int
 
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
-            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False):
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, pairs=False):
         lrows, dim_x = d.shape
         gdim_y = lrows if gdim_y is None else gdim_y
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (16 if pairs else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
         assert rc == 0
@@ -131,3 +131,23 @@ def test_tilings_partition_the_row_range(emu):
                 assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
                 counts[balance] = n
             assert counts[10] >= counts[0]
+
+
+@pytest.mark.parametrize("ns", [12, 16])
+@pytest.mark.parametrize("dim_x,dim_y,rows", [(420, 260, 40), (257, 300, 64), (640, 150, 24)])
+def test_stage_paired_pipeline_on_interior_tiles(emu, oracle, ns, dim_x, dim_y, rows):
+    """sor_stream_pairs.h: interior tiles relax two pipeline stages per packed operation (register
+    pairs {row r, row r - NS/2 - 2}); boundary tiles keep the scalar EDGE path.  Bit-exact against
+    the oracle from zero and from a given p, dx = 1 and dx != 1, NaN-poisoned state."""
+    rng = np.random.default_rng(ns * 7 + dim_x)
+    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    assert_bit_equal(emu(None, d, ns, rows=rows, pairs=True), oracle.poisson_solve(d, 1.0, ns // 2, OMEGA),
+                     "pairs, from zero")
+    assert_bit_equal(emu(p0, d, ns, rows=rows, pairs=True), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA),
+                     "pairs, continue")
+    assert_bit_equal(emu(p0, d, ns, rows=rows, pairs=True, dx=0.5, omega=np.float32(1.4)),
+                     oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "pairs, dx and omega")
+    if dim_x % 2 == 0:
+        assert_bit_equal(emu(p0, d, ns, rows=rows, pairs=True, vec2=True),
+                         oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "pairs, vec2 access")
