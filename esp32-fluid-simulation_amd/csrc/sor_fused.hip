@@ -105,7 +105,7 @@ struct Lane2 : WaveCommon {
                                            : sor::ring_rows(NS) * 2 * 64;
 
     float *ring;         // this lane's word of ring slot 0 / plane 0 in LDS
-    int lane_id;
+    __attribute__((address_space(3))) v2f *ring2;  // the same memory as the paired ring's 8-byte elements
     int off_a, off_b;    // byte offsets of the clamped load columns of cell a / b
     int off_out;         // byte offset of the true column of cell a
     bool a_out, b_out;   // columns this tile is responsible for (exact interior, in the domain)
@@ -113,7 +113,7 @@ struct Lane2 : WaveCommon {
     __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
     {
         ring = ring_base + lane;
-        lane_id = lane;
+        ring2 = (__attribute__((address_space(3))) v2f *)ring_base + lane;
         const int xa = x0 + 2 * lane;
         if (VEC) {  // dim_x even: the pair is inside or outside as a whole
             off_a = 4 * min(max(xa, 0), dim_x - 2);
@@ -161,13 +161,11 @@ struct Lane2 : WaveCommon {
     __device__ __forceinline__ V2 from_upper_lane2(V2 p) const { return V2{lane_above_bc(p.x), lane_above_bc(p.y)}; }
     // paired ring: [R slots][2 planes][64 lanes] of {d[r], d[r - KP]} (8-byte DS accesses); the
     // lane's element of slot 0 / plane 0 sits at the same LDS address as the scalar ring's base
-    __device__ __forceinline__ V2 *ring2() const { return reinterpret_cast<V2 *>(ring - lane_id) + lane_id; }
-    __device__ __forceinline__ void ring_store2(int slot, int plane, V2 x) const { ring2()[(slot * 2 + plane) * 64] = x; }
-    __device__ __forceinline__ V2 ring_load_pair(int slot, int plane) const { return ring2()[(slot * 2 + plane) * 64]; }
-    __device__ __forceinline__ V ring_load_lo(int slot, int plane) const
-    {
-        return reinterpret_cast<const float *>(&ring2()[(slot * 2 + plane) * 64])[0];
-    }
+    // (explicit LDS address space: through a generic pointer these stores could alias the
+    // pipeline's private arrays, which then stay in scratch)
+    __device__ __forceinline__ void ring_store2(int slot, int plane, V2 x) const { ring2[(slot * 2 + plane) * 64] = x; }
+    __device__ __forceinline__ V2 ring_load_pair(int slot, int plane) const { return ring2[(slot * 2 + plane) * 64]; }
+    __device__ __forceinline__ V ring_load_lo(int slot, int plane) const { return ring2[(slot * 2 + plane) * 64].x; }
 
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {

@@ -46,6 +46,7 @@ struct PairPipe {
     V2 O[pair_ring_rows(NS)];
     V pa[B::kPrefetch], pb[B::kPrefetch];
     V da[B::kPrefetch], db[B::kPrefetch];
+    V old0, old1;  // d[y - KP] of the row about to enter, both planes (read back one iteration ahead)
 };
 
 // One relaxation of a pair, interior formula (poisson.cpp:101-112), each half rounded as the
@@ -81,8 +82,11 @@ SFL_HD void iterate_pairs(B &bk, PairPipe<B, NS> &pp, float dx, float omega, flo
         constexpr bool ev = is_even(U);
         constexpr int from = wrapn(U - KP, RING);
         // plane 0: d of the E cell, plane 1: d of the O cell; rows y and y - KP have equal parity
-        bk.ring_store2(U, 0, bk.make2(ev ? fa : fb, bk.ring_load_lo(from, 0)));
-        bk.ring_store2(U, 1, bk.make2(ev ? fb : fa, bk.ring_load_lo(from, 1)));
+        bk.ring_store2(U, 0, bk.make2(ev ? fa : fb, pp.old0));
+        bk.ring_store2(U, 1, bk.make2(ev ? fb : fa, pp.old1));
+        // next iteration's read-back starts now: its slot was written KP - 1 iterations ago
+        pp.old0 = bk.ring_load_lo(wrapn(U + 1 - KP, RING), 0);
+        pp.old1 = bk.ring_load_lo(wrapn(U + 1 - KP, RING), 1);
         bk.load_row(y + kPrefetch, pp.pa[P], pp.pb[P], pp.da[P], pp.db[P]);
         if (ZERO_IN) a = b = bk.splat(0.0f);
         pp.E[U] = bk.make2(ev ? a : b, bk.lo(pp.E[from]));
@@ -155,6 +159,9 @@ SFL_HD void stream_tile_pairs(B &bk, float dx, float omega, float one_minus_omeg
 
 #pragma unroll
     for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
+    // slots never written yet: whatever they hold only reaches rows below the tile
+    pp.old0 = bk.ring_load_lo(wrapn(0 - (NS / 2 + 2), RING), 0);
+    pp.old1 = bk.ring_load_lo(wrapn(0 - (NS / 2 + 2), RING), 1);
 
     constexpr auto us = std::make_integer_sequence<int, RING>{};
     for (; y + RING <= y_stop; y += RING)
