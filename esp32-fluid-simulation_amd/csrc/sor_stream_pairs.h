@@ -63,14 +63,62 @@ SFL_HD typename B::V2 relax_pair(const B &bk, float dx, float omega, float one_m
     return bk.scale2(one_minus_omega, own) + bk.scale2(omega, gs);
 }
 
+// Packed stage M of the iteration that receives row y (U = y mod RING): every index below is a
+// constant expression (a runtime `for m` loop that is unrolled later leaves the arrays dynamically
+// indexed for the first optimisation passes, and the small ones are then not split into registers).
+template <class B, int NS, bool DX1, bool GUARD_STORE, int U, int M>
+SFL_HD void pair_stage(B &bk, PairPipe<B, NS> &pp, float dx, float omega, float one_minus_omega, int y,
+                       int out_begin, int out_end)
+{
+    using V2 = typename B::V2;
+    constexpr int RING = pair_ring_rows(NS);
+    constexpr int Q = NS / 4;
+    constexpr int KP = NS / 2 + 2;
+    // ---- E: lower half = E_M of row y - (2M - 1), upper half = E_{M+Q} of that row - KP ----
+    {
+        constexpr int rel = U - (2 * M - 1);
+        constexpr int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
+        constexpr bool ev = is_even(rel);
+        const V2 oc = pp.O[i0];
+        const V2 w = ev ? bk.from_lower_lane2(oc) : oc;
+        const V2 e = ev ? oc : bk.from_upper_lane2(oc);
+        const V2 d = bk.ring_load_pair(i0, 0);
+        pp.E[i0] = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.E[i0], w, e, pp.O[im], pp.O[ip], d);
+    }
+    // ---- O: lower half = O_M of row y - 2M, upper half = O_{M+Q} of that row - KP ----
+    {
+        constexpr int rel = U - 2 * M;
+        const int r_hi = y - 2 * M - KP;  // M == Q: y - NS - 2, the row that leaves
+        constexpr int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
+        constexpr bool ev = is_even(rel);
+        const V2 oc = pp.E[i0];
+        const V2 w = ev ? oc : bk.from_lower_lane2(oc);
+        const V2 e = ev ? bk.from_upper_lane2(oc) : oc;
+        const V2 d = bk.ring_load_pair(i0, 1);
+        const V2 res = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.O[i0], w, e, pp.E[im], pp.E[ip], d);
+        pp.O[i0] = res;
+        if (M == Q && (!GUARD_STORE || (r_hi >= out_begin && r_hi < out_end))) {
+            if (ev)
+                bk.store_row(r_hi, bk.hi(oc), bk.hi(res));
+            else
+                bk.store_row(r_hi, bk.hi(res), bk.hi(oc));
+        }
+    }
+}
+
+template <class B, int NS, bool DX1, bool GUARD_STORE, int U, int... Ms>
+SFL_HD void pair_stages(B &bk, PairPipe<B, NS> &pp, float dx, float omega, float one_minus_omega, int y,
+                        int out_begin, int out_end, std::integer_sequence<int, Ms...>)
+{
+    (pair_stage<B, NS, DX1, GUARD_STORE, U, Ms + 1>(bk, pp, dx, omega, one_minus_omega, y, out_begin, out_end), ...);
+}
+
 template <class B, int NS, bool DX1, bool ZERO_IN, bool GUARD_STORE, int U>
 SFL_HD void iterate_pairs(B &bk, PairPipe<B, NS> &pp, float dx, float omega, float one_minus_omega,
                           int y, int out_begin, int out_end)
 {
     using V = typename B::V;
-    using V2 = typename B::V2;
     constexpr int RING = pair_ring_rows(NS);
-    constexpr int Q = NS / 4;
     constexpr int KP = NS / 2 + 2;
     constexpr int kPrefetch = B::kPrefetch;
     constexpr int P = U % kPrefetch;
@@ -92,42 +140,8 @@ SFL_HD void iterate_pairs(B &bk, PairPipe<B, NS> &pp, float dx, float omega, flo
         pp.E[U] = bk.make2(ev ? a : b, bk.lo(pp.E[from]));
         pp.O[U] = bk.make2(ev ? b : a, bk.lo(pp.O[from]));
     }
-
-#pragma unroll
-    for (int m = 1; m <= Q; ++m) {
-        // ---- E: lower half = E_m of row y - (2m - 1), upper half = E_{m+Q} of that row - KP ----
-        {
-            const int rel = U - (2 * m - 1);
-            const int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
-            const bool ev = is_even(rel);
-            const V2 oc = pp.O[i0];
-            const V2 w = ev ? bk.from_lower_lane2(oc) : oc;
-            const V2 e = ev ? oc : bk.from_upper_lane2(oc);
-            const V2 d = bk.ring_load_pair(i0, 0);
-            pp.E[i0] = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.E[i0], w, e, pp.O[im],
-                                          pp.O[ip], d);
-        }
-        // ---- O: lower half = O_m of row y - 2m, upper half = O_{m+Q} of that row - KP ----
-        {
-            const int rel = U - 2 * m;
-            const int r_hi = y - 2 * m - KP;  // m == Q: y - NS - 2, the row that leaves
-            const int i0 = wrapn(rel, RING), im = wrapn(rel - 1, RING), ip = wrapn(rel + 1, RING);
-            const bool ev = is_even(rel);
-            const V2 oc = pp.E[i0];
-            const V2 w = ev ? oc : bk.from_lower_lane2(oc);
-            const V2 e = ev ? bk.from_upper_lane2(oc) : oc;
-            const V2 d = bk.ring_load_pair(i0, 1);
-            const V2 res = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.O[i0], w, e,
-                                              pp.E[im], pp.E[ip], d);
-            pp.O[i0] = res;
-            if (m == Q && (!GUARD_STORE || (r_hi >= out_begin && r_hi < out_end))) {
-                if (ev)
-                    bk.store_row(r_hi, bk.hi(oc), bk.hi(res));
-                else
-                    bk.store_row(r_hi, bk.hi(res), bk.hi(oc));
-            }
-        }
-    }
+    pair_stages<B, NS, DX1, GUARD_STORE, U>(bk, pp, dx, omega, one_minus_omega, y, out_begin, out_end,
+                                             std::make_integer_sequence<int, NS / 4>{});
 }
 
 template <class B, int NS, bool DX1, bool ZERO_IN, bool PARTIAL, bool GUARD_STORE, int... Us>
