@@ -99,13 +99,10 @@ struct Lane2 : WaveCommon {
     static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6;
     // LDS per wave: the scalar ring (RING rows x 2 planes x 64 lanes x 4 B) or, at the depths that
     // have the paired pipeline, its ring of 8-byte pairs
-    static constexpr int kRingFloats = kBuildPairs && sor::pairs_supported(NS)
-                                           ? (sor::pair_ring_rows(NS) * 4 > sor::ring_rows(NS) * 2
-                                                  ? sor::pair_ring_rows(NS) * 4 : sor::ring_rows(NS) * 2) * 64
-                                           : sor::ring_rows(NS) * 2 * 64;
+    static constexpr int kRingFloats = (kBuildPairs && sor::pairs_supported(NS) ? sor::pair_ring_rows(NS)
+                                                                                 : sor::ring_rows(NS)) * 2 * 64;
 
     float *ring;         // this lane's word of ring slot 0 / plane 0 in LDS
-    __attribute__((address_space(3))) v2f *ring2;  // the same memory as the paired ring's 8-byte elements
     int off_a, off_b;    // byte offsets of the clamped load columns of cell a / b
     int off_out;         // byte offset of the true column of cell a
     bool a_out, b_out;   // columns this tile is responsible for (exact interior, in the domain)
@@ -113,7 +110,6 @@ struct Lane2 : WaveCommon {
     __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
     {
         ring = ring_base + lane;
-        ring2 = (__attribute__((address_space(3))) v2f *)ring_base + lane;
         const int xa = x0 + 2 * lane;
         if (VEC) {  // dim_x even: the pair is inside or outside as a whole
             off_a = 4 * min(max(xa, 0), dim_x - 2);
@@ -159,13 +155,10 @@ struct Lane2 : WaveCommon {
     __device__ __forceinline__ V2 scale2(float s, V2 v) const { return s * v; }
     __device__ __forceinline__ V2 from_lower_lane2(V2 p) const { return V2{lane_below_bc(p.x), lane_below_bc(p.y)}; }
     __device__ __forceinline__ V2 from_upper_lane2(V2 p) const { return V2{lane_above_bc(p.x), lane_above_bc(p.y)}; }
-    // paired ring: [R slots][2 planes][64 lanes] of {d[r], d[r - KP]} (8-byte DS accesses); the
-    // lane's element of slot 0 / plane 0 sits at the same LDS address as the scalar ring's base
-    // (explicit LDS address space: through a generic pointer these stores could alias the
-    // pipeline's private arrays, which then stay in scratch)
-    __device__ __forceinline__ void ring_store2(int slot, int plane, V2 x) const { ring2[(slot * 2 + plane) * 64] = x; }
-    __device__ __forceinline__ V2 ring_load_pair(int slot, int plane) const { return ring2[(slot * 2 + plane) * 64]; }
-    __device__ __forceinline__ V ring_load_lo(int slot, int plane) const { return ring2[(slot * 2 + plane) * 64].x; }
+    __device__ __forceinline__ V2 ring_load2(int slot_lo, int slot_hi, int plane) const
+    {
+        return V2{ring[(slot_lo * 2 + plane) * 64], ring[(slot_hi * 2 + plane) * 64]};
+    }
 
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
@@ -316,6 +309,9 @@ struct Lane4 : WaveCommon {
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads)
+#ifdef SFL_EXPERIMENTAL_PAIRS_WAVES
+__attribute__((amdgpu_waves_per_eu(SFL_EXPERIMENTAL_PAIRS_WAVES, SFL_EXPERIMENTAL_PAIRS_WAVES)))
+#endif
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t,
                  SorParams prm)
 {

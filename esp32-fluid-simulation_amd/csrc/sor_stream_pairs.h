@@ -17,12 +17,11 @@
 // row parity of both halves equal, so both take the same DPP shift.  Consequence: a row leaves
 // NS + 2 iterations after it entered (two more warm-up rows than the scalar pipeline).
 //
-// The right-hand side waits in LDS as PAIRS too: slot (r mod R) holds, per colour plane and lane,
-// the 8-byte element {d[r], d[r - KP]}, so a packed stage fetches its operand pair with one
-// ds_read_b64 straight into an aligned register pair.  When row y enters, d[y - KP] is read back
-// from the lower half of slot y - KP and written next to d[y].  A slot is needed KP + 1 iterations
-// (as long as the pair P[r] is worked on, plus the read-back), so R = NS/2 + 4 rounded up to a
-// multiple of 6 is both the ring size and the unroll factor.
+// The right-hand side waits in the same kind of LDS ring as in the scalar pipeline (one 4-byte
+// word per row, colour plane and lane), NS + 3 rows deep; a packed stage fetches its operand pair
+// with two reads (slot of row r, slot of row r - KP).  Measured alternatives: a ring of 8-byte
+// {d[r], d[r - KP]} elements (one ds_read_b64 per operand pair, d[y - KP] read back and rewritten
+// when row y enters) is much slower (LDS bound: 364 against 210 us per launch at NS = 16).
 //
 // Every neighbour a half reads is the same half of the neighbouring row's pair, at exactly the
 // version the scalar pipeline reads (the argument of sor_stream_core.h applies to each half), so
@@ -33,8 +32,9 @@
 namespace sfl {
 namespace sor {
 
-// pairs (registers and LDS slots) alive at once: NS/2 + 4, rounded up to a multiple of 6
-constexpr int pair_ring_rows(int ns) { return ((ns / 2 + 4 + 5) / 6) * 6; }
+// rows of d alive at once in the paired pipeline (NS + 3), rounded up to a multiple of 6; also the
+// unroll factor and the modulus of the register arrays
+constexpr int pair_ring_rows(int ns) { return ((ns + 3 + 5) / 6) * 6; }
 // built for the depths where it pays (NS % 4 == 0 is required by the design)
 constexpr bool pairs_supported(int ns) { return ns == 12 || ns == 16; }
 
@@ -46,7 +46,6 @@ struct PairPipe {
     V2 O[pair_ring_rows(NS)];
     V pa[B::kPrefetch], pb[B::kPrefetch];
     V da[B::kPrefetch], db[B::kPrefetch];
-    V old0, old1;  // d[y - KP] of the row about to enter, both planes (read back one iteration ahead)
 };
 
 // One relaxation of a pair, interior formula (poisson.cpp:101-112), each half rounded as the
@@ -82,7 +81,7 @@ SFL_HD void pair_stage(B &bk, PairPipe<B, NS> &pp, float dx, float omega, float 
         const V2 oc = pp.O[i0];
         const V2 w = ev ? bk.from_lower_lane2(oc) : oc;
         const V2 e = ev ? oc : bk.from_upper_lane2(oc);
-        const V2 d = bk.ring_load_pair(i0, 0);
+        const V2 d = bk.ring_load2(i0, wrapn(rel - KP, RING), 0);
         pp.E[i0] = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.E[i0], w, e, pp.O[im], pp.O[ip], d);
     }
     // ---- O: lower half = O_M of row y - 2M, upper half = O_{M+Q} of that row - KP ----
@@ -94,7 +93,7 @@ SFL_HD void pair_stage(B &bk, PairPipe<B, NS> &pp, float dx, float omega, float 
         const V2 oc = pp.E[i0];
         const V2 w = ev ? oc : bk.from_lower_lane2(oc);
         const V2 e = ev ? bk.from_upper_lane2(oc) : oc;
-        const V2 d = bk.ring_load_pair(i0, 1);
+        const V2 d = bk.ring_load2(i0, wrapn(rel - KP, RING), 1);
         const V2 res = relax_pair<B, DX1>(bk, dx, omega, one_minus_omega, pp.O[i0], w, e, pp.E[im], pp.E[ip], d);
         pp.O[i0] = res;
         if (M == Q && (!GUARD_STORE || (r_hi >= out_begin && r_hi < out_end))) {
@@ -129,12 +128,8 @@ SFL_HD void iterate_pairs(B &bk, PairPipe<B, NS> &pp, float dx, float omega, flo
         const V fa = pp.da[P], fb = pp.db[P];
         constexpr bool ev = is_even(U);
         constexpr int from = wrapn(U - KP, RING);
-        // plane 0: d of the E cell, plane 1: d of the O cell; rows y and y - KP have equal parity
-        bk.ring_store2(U, 0, bk.make2(ev ? fa : fb, pp.old0));
-        bk.ring_store2(U, 1, bk.make2(ev ? fb : fa, pp.old1));
-        // next iteration's read-back starts now: its slot was written KP - 1 iterations ago
-        pp.old0 = bk.ring_load_lo(wrapn(U + 1 - KP, RING), 0);
-        pp.old1 = bk.ring_load_lo(wrapn(U + 1 - KP, RING), 1);
+        bk.ring_store(U, 0, ev ? fa : fb);  // plane 0: d of the E cell
+        bk.ring_store(U, 1, ev ? fb : fa);  // plane 1: d of the O cell
         bk.load_row(y + kPrefetch, pp.pa[P], pp.pb[P], pp.da[P], pp.db[P]);
         if (ZERO_IN) a = b = bk.splat(0.0f);
         pp.E[U] = bk.make2(ev ? a : b, bk.lo(pp.E[from]));
@@ -163,7 +158,7 @@ SFL_HD void stream_tile_pairs(B &bk, float dx, float omega, float one_minus_omeg
     static_assert(pairs_supported(NS) && NS % 4 == 0, "the paired pipeline needs NS % 4 == 0");
     constexpr int RING = pair_ring_rows(NS);
     constexpr int kPrefetch = B::kPrefetch;
-    static_assert(RING % 6 == 0 && 6 % kPrefetch == 0 && RING >= NS / 2 + 4, "ring geometry");
+    static_assert(RING % 6 == 0 && 6 % kPrefetch == 0 && RING >= NS + 3, "ring geometry");
     PairPipe<B, NS> pp;
     bk.poison(pp);
 
@@ -173,9 +168,6 @@ SFL_HD void stream_tile_pairs(B &bk, float dx, float omega, float one_minus_omeg
 
 #pragma unroll
     for (int u = 0; u < kPrefetch; ++u) bk.load_row(y + u, pp.pa[u], pp.pb[u], pp.da[u], pp.db[u]);
-    // slots never written yet: whatever they hold only reaches rows below the tile
-    pp.old0 = bk.ring_load_lo(wrapn(0 - (NS / 2 + 2), RING), 0);
-    pp.old1 = bk.ring_load_lo(wrapn(0 - (NS / 2 + 2), RING), 1);
 
     constexpr auto us = std::make_integer_sequence<int, RING>{};
     for (; y + RING <= y_stop; y += RING)

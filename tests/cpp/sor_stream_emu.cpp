@@ -174,24 +174,9 @@ struct EmuBackend {
     }
     V2 from_lower_lane2(const V2 &p) const { return {from_lower_lane(p.x), from_lower_lane(p.y)}; }
     V2 from_upper_lane2(const V2 &p) const { return {from_upper_lane(p.x), from_upper_lane(p.y)}; }
-    // paired ring (sor_stream_pairs.h): [slot][plane][half][lane], sharing the scalar ring's storage
-    void ring_store2(int slot, int plane, const V2 &x)
+    V2 ring_load2(int slot_lo, int slot_hi, int plane) const
     {
-        std::memcpy(&ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], x.x.l, sizeof(x.x.l));
-        std::memcpy(&ring[(size_t)((slot * 2 + plane) * 2 + 1) * 64], x.y.l, sizeof(x.y.l));
-    }
-    V2 ring_load_pair(int slot, int plane) const
-    {
-        V2 r;
-        std::memcpy(r.x.l, &ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], sizeof(r.x.l));
-        std::memcpy(r.y.l, &ring[(size_t)((slot * 2 + plane) * 2 + 1) * 64], sizeof(r.y.l));
-        return r;
-    }
-    V ring_load_lo(int slot, int plane) const
-    {
-        V r;
-        std::memcpy(r.l, &ring[(size_t)((slot * 2 + plane) * 2 + 0) * 64], sizeof(r.l));
-        return r;
+        return {ring_load(slot_lo, plane), ring_load(slot_hi, plane)};
     }
 };
 
@@ -237,8 +222,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.out_hi = bk.x0 + t.tile_cols - t.halo_cols;
             bk.vec2 = vec2;
             bk.poison_on = poison;
-            bk.ring.assign((size_t)(pairs_supported(NS) && pair_ring_rows(NS) * 2 > ring_rows(NS)
-                                        ? pair_ring_rows(NS) * 2 : ring_rows(NS)) * 2 * 64,
+            bk.ring.assign((size_t)(pairs_supported(NS) ? pair_ring_rows(NS) : ring_rows(NS)) * 2 * 64,
                            poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
             const int r0 = rect.r0, r1 = rect.r1;
             bk.tile_r0 = r0;
