@@ -8,39 +8,50 @@ on a `size` x `size` fp32 grid held in HBM -- BASELINE.json's headline metric "c
 sweep)", config[2] "8192x8192 fp32, 80 SOR iters/step" at N = 1 and config[3] (same grid, row-slab
 split with RCCL halo exchange) at N > 1, i.e. STRONG scaling.  After the timed region the full
 sim step (advect, divergence, solve, gradient, dye advect: ino:252-287) is timed separately and
-reported as `sim_steps_per_sec` (the metric's "+ steps/sec" half).  Before the W warm-up steps the
-device is kept busy with ~80 ms of the same solves (untimed, `priming_solves` in the output,
-`--no-priming` to skip) so that it runs at its sustained clocks, as in a running simulation.
+reported as `sim_steps_per_sec` (the metric's "+ steps/sec" half).
 
-Launch: N = 1 directly; N > 1 through `python -m torch.distributed.run --nproc-per-node N ...`,
-one process per GPU.  torch.distributed (gloo) carries only the bootstrap (RCCL unique id,
-barriers, max-over-ranks); every halo byte moves through RCCL send/recv issued by the C++
-library on the solver's own HIP stream.
+Launch.  `python bench.py --gpus N` works as typed: for N > 1 this process touches no GPU, starts
+N child processes (one per GPU; RANK / LOCAL_RANK / WORLD_SIZE in their environment), relays
+rank 0's JSON line and exits with the worst child's status.  Started by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` each process finds
+WORLD_SIZE in its environment and is a rank directly.  The ranks never import torch: host-side
+coordination (RCCL unique id, barriers, max over ranks) is a small TCP all-gather
+(esp32-fluid-simulation_amd/rendezvous.py); every halo byte moves through RCCL send/recv issued by
+the C++ library.
 
 Output: ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      algorithmic bytes (16 B per cell-iteration) / avg kernel duration
-                measured with HIP events on the solver's stream, against the 8 TB/s HBM peak
+  parity        the pressure field left by the LAST TIMED solve, downloaded and compared bit for
+                bit with the reference CPU loop run on the very same right-hand side (downloaded
+                from the GPU); the process exits non-zero on a mismatch
+  roofline      the bound that binds the temporally blocked kernel (VALU issue), the measured HBM
+                traffic fraction, and the SURVEY 8d algorithmic-bytes figure (labelled as a ratio)
   cpu_baseline  the reference's own CPU loop (oracle/_ref, or the oracle port) on this host,
-                1 thread, bounded sample; N = 1 only
+                1 thread: the parity solve itself is the timed sample; N = 1 only
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
+PKG = "esp32-fluid-simulation_amd"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 SOR_BYTES_PER_CELL_ITER = 16   # SURVEY.md 8(d)
 SOR_FLOPS_PER_CELL_ITER = 8    # one relaxation of an interior cell: 3 neighbour adds, rhs subtract,
                                # scale by -1/4, two omega products and their sum (never fused);
                                # SURVEY 8a13 counts 10: dx*d is exact at dx = 1, 1-omega is hoisted
 VALU_CLOCK_GHZ = 2.4           # MI355X max engine clock (MI355X_MICROARCH.md)
+# algorithmic bytes per cell of the streaming operators (SURVEY.md 8d / BASELINE.md 3)
+OP_BYTES_PER_CELL = {"advect_velocity": 16, "calculate_divergence": 12, "subtract_gradient": 20,
+                     "advect_color": 32}
 
 
 def synthetic_velocity(dim_x, row_begin, row_end, seed=12345, vamp=100.0):
@@ -69,32 +80,37 @@ def synthetic_color(dim_x, row_begin, row_end, seed=777):
     return ((h >> np.uint64(20)) & np.uint64(0x7FFFFFFF)).astype(np.uint32)   # raw < 2^31
 
 
-def cpu_baseline(size, iters, budget_s=12.0):
-    """Reference CPU loop (1 thread) on a bounded sample of the same workload: whole
-    poisson_solve calls on the same grid, repeated until ~budget_s of CPU time is spent."""
+def cpu_path():
     from oracle import loader  # checker / baseline only
-    path = loader.reference() if loader.reference_available() else loader.port()
-    d = np.random.default_rng(5).standard_normal((size, size)).astype(np.float32) * np.float32(0.1)
+    return loader.reference() if loader.reference_available() else loader.port()
+
+
+def cpu_reference_solve(d, iters, min_seconds=8.0):
+    """The reference CPU loop (1 thread) on the SAME right-hand side the GPU solved: returns its
+    pressure field (the parity check's expectation) and the cpu_baseline record.  The first call is
+    both; it is repeated (timing only) until ~min_seconds of CPU work have been spent."""
+    path = cpu_path()
+    dim_y, dim_x = d.shape
+    om = np.float32(1.96)
     t0 = time.perf_counter()
-    path.poisson_solve(d, 1.0, 2, np.float32(1.96))
-    per_iter = (time.perf_counter() - t0) / 2
-    run_iters = int(max(2, min(iters, budget_s / max(per_iter, 1e-9))))
-    reps = int(max(1, round(budget_s / max(per_iter * run_iters, 1e-9))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        path.poisson_solve(d, 1.0, run_iters, np.float32(1.96))
-    dt = time.perf_counter() - t0
-    return {"value": size * size * run_iters * reps / dt, "unit": "cell-iters/s", "cores": 1,
-            "kind": path.kind,
-            "sample": f"{reps} x poisson_solve {size}x{size} fp32, {run_iters} iters each, 1 thread, "
-                      f"{dt:.1f} s ({'unmodified reference sources' if path.kind == 'reference' else 'oracle C port'}, "
-                      f"g++/gcc -O2 -ffp-contract=off)"}
+    want = path.poisson_solve(d, 1.0, iters, om)
+    spent, reps = time.perf_counter() - t0, 1
+    while spent < min_seconds and reps < 50:
+        t0 = time.perf_counter()
+        path.poisson_solve(d, 1.0, iters, om)
+        spent += time.perf_counter() - t0
+        reps += 1
+    what = "unmodified reference sources" if path.kind == "reference" else "oracle C port"
+    return want, {"value": dim_x * dim_y * iters * reps / spent, "unit": "cell-iters/s", "cores": 1,
+                  "kind": path.kind,
+                  "sample": f"{reps} x poisson_solve {dim_x}x{dim_y} fp32, {iters} iters each, on the GPU "
+                            f"run's own right-hand side, 1 thread, {spent:.1f} s ({what}, g++/gcc -O2 "
+                            f"-ffp-contract=off); the first of them is the parity expectation"}
 
 
 def cpu_operator_times(dim_x, dim_y, iters):
     """Per-operator wall time of the reference CPU path for ONE sim step (1 thread), ms."""
-    from oracle import loader
-    path = loader.reference() if loader.reference_available() else loader.port()
+    path = cpu_path()
     v = synthetic_velocity(dim_x, 0, dim_y)
     c = synthetic_color(dim_x, 0, dim_y)
     dt, om = np.float32(1 / 30.0), np.float32(1.96)
@@ -114,8 +130,9 @@ def cpu_operator_times(dim_x, dim_y, iters):
     return {"grid": [dim_x, dim_y], "iters": iters, "kind": path.kind, "ms": out}
 
 
-def gpu_operator_times(s, capi, iters, reps=3):
-    """Per-operator HIP-event time of one sim step on this rank's slab, microseconds."""
+def gpu_operator_times(s, iters, cells, reps=3):
+    """Per-operator HIP-event time of one sim step on this rank's slab (best of `reps`), with the
+    streaming operators' algorithmic bytes / time against the HBM peak next to it."""
     dt, om = np.float32(1 / 30.0), np.float32(1.96)
     ops = [("advect_velocity", lambda: s.advect_velocity(dt, True)),
            ("calculate_divergence", lambda: s.calculate_divergence(1.0)),
@@ -131,7 +148,12 @@ def gpu_operator_times(s, capi, iters, reps=3):
             fn()
             ms = s.timer_stop()
             best = ms if best is None else min(best, ms)
-        out[name] = best * 1e3
+        rec = {"us": best * 1e3}
+        if name in OP_BYTES_PER_CELL:
+            gbs = OP_BYTES_PER_CELL[name] * cells / (best * 1e-3) / 1e9
+            rec.update({"algorithmic_bytes_per_cell": OP_BYTES_PER_CELL[name], "algorithmic_GBps": gbs,
+                        "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+        out[name] = rec
     return out
 
 
@@ -145,21 +167,21 @@ def host_cpu_model():
     return "unknown"
 
 
-def pmc_traffic(size, fuse, lane_cells, world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+def pmc_record(grid, fuse, world):
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json), or None when no entry matches this exact configuration."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
     except Exception:
         return None
+    best = None
     for e in table:
-        if (e["grid"] == [size, size] and e["fuse"] == fuse and e["lane_cells"] == lane_cells
-                and e["n_gpus"] == world):
-            return e
-    return None
+        if e["grid"] == list(grid) and e["fuse"] == fuse and e["n_gpus"] == world:
+            best = e    # later entries (later rounds) win
+    return best
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -170,67 +192,115 @@ def main():
     ap.add_argument("--fuse", type=int, default=0, help="SOR half-sweeps fused per launch (0 = library default)")
     ap.add_argument("--sor-kernel", type=int, default=0)
     ap.add_argument("--sor-rows", type=int, default=0)
+    ap.add_argument("--sor-halo", type=int, default=0, help="rows of p exchanged per superstep (0 = auto)")
     ap.add_argument("--lane-cells", type=int, default=0, help="cells per lane of the fused kernel (0 auto, 2, 4)")
     ap.add_argument("--sim-steps", type=int, default=3, help="full sim steps timed after the main region")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the reference CPU solve (and with it the parity check)")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the reference solve on rank 0")
     ap.add_argument("--no-priming", action="store_true",
                     help="skip the ~80 ms of untimed solves that bring the GPU to its sustained clocks")
     ap.add_argument("--no-fuse-projection", action="store_true",
                     help="sim step: separate subtract_gradient and dye-advection kernels (A/B)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous plumbing only: the ranks touch no GPU (CPU test)")
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------
+# parent: `python bench.py --gpus N` with N > 1 and no launcher around it
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Start one child per GPU and relay rank 0's JSON line.  This process never touches a GPU
+    (no HIP call, not even a device count): the children are fresh processes, nothing that has
+    initialised a GPU is ever replaced or forked."""
+    import socket
+    with socket.socket() as s:      # a free port for MASTER_PORT (RCCL's bootstrap picks its own)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n = args.gpus
+    base = dict(os.environ)
+    base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "LOCAL_WORLD_SIZE": str(n), "SFL_RDZV_KEY": f"{os.getpid()}_{port}",
+                 "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the JSON line; everybody else's goes to our stderr
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait()
+        worst = rc if (rc != 0 and worst == 0) else worst
+    line = None
+    for l in (out0 or "").splitlines():
+        if l.startswith("{"):
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+def run_rank(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if "SFL_BENCH_DEVICE" in os.environ:   # bring-up aid: several ranks on one device
         local_rank = int(os.environ["SFL_BENCH_DEVICE"])
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs the torch.distributed.run launcher (WORLD_SIZE={world})")
-        args.gpus = world
+    args.gpus = world
 
-    # load the product library (system ROCm runtime) before torch pulls in its own copy
-    sfl = importlib.import_module("esp32-fluid-simulation_amd")
+    sfl = importlib.import_module(PKG)
+    from importlib import import_module
+    rdzv = import_module(PKG + ".rendezvous").Rendezvous(rank, world)
     capi = sfl.capi
-    if sfl.device_count() < 1:
-        sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
 
-    import torch
-    import torch.distributed as dist
-    if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
-        torch.cuda.set_device(local_rank)   # torch.cuda.synchronize() below must mean THIS rank's GPU
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.dry_run:   # plumbing check without a GPU: broadcast, barrier, max, one JSON line
+        token = rdzv.broadcast_bytes(os.urandom(16) if rank == 0 else None)
+        rdzv.barrier()
+        top = rdzv.max([float(rank), 1.0])
+        ranks = rdzv.all_gather({"rank": rank, "token": token.hex()})
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank": top[0],
+                              "tokens_agree": len({r["token"] for r in ranks}) == 1,
+                              "ranks": [r["rank"] for r in ranks]}), flush=True)
+        rdzv.barrier()
+        rdzv.close()
+        return 0
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    if sfl.device_count() <= local_rank:
+        sys.exit(f"bench.py rank {rank}: device {local_rank} not visible ({sfl.device_count()} devices): "
+                 "the product path has no CPU fallback")
 
     size, iters = args.size, args.iters
     dim_y = args.dim_y or size
     s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
-    if args.fuse:
-        s.set_option(capi.OPT_SOR_FUSE, args.fuse)
-    if args.sor_kernel:
-        s.set_option(capi.OPT_SOR_KERNEL, args.sor_kernel)
-    if args.sor_rows:
-        s.set_option(capi.OPT_SOR_ROWS, args.sor_rows)
-    if args.lane_cells:
-        s.set_option(capi.OPT_SOR_LANE_CELLS, args.lane_cells)
+    for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
+                     (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
+                     (capi.OPT_SOR_HALO, args.sor_halo)):
+        if val:
+            s.set_option(opt, val)
     if args.no_fuse_projection:
         s.set_option(capi.OPT_FUSE_PROJECTION, 0)
     if world > 1:
-        uid = [sfl.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        uid = rdzv.broadcast_bytes(sfl.comm_unique_id() if rank == 0 else None)
         # RCCL prints a version banner on stdout while the communicator comes up; keep stdout
         # clean for the ONE JSON line by pointing fd 1 at stderr for the duration of the call
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            s.comm_attach(uid[0])
+            s.comm_attach(uid)
         finally:
             os.dup2(saved, 1)
             os.close(saved)
@@ -241,59 +311,94 @@ def main():
     s.calculate_divergence(1.0)     # right-hand side = divergence of the velocity
     s.synchronize()
 
-    def sync_all():
-        s.synchronize()
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
-
     omega = np.float32(1.96)
+    cells = size * dim_y
+
+    def timed_region():
+        """W untimed + K timed solves, barrier + device sync on both sides, max over ranks."""
+        for _ in range(args.warmup):
+            s.poisson_solve(1.0, iters, omega)
+        s.synchronize()
+        rdzv.barrier()
+        t0 = time.perf_counter()
+        s.timer_start()
+        for _ in range(args.steps):
+            s.poisson_solve(1.0, iters, omega)
+        ev_ms = s.timer_stop()
+        s.synchronize()
+        rdzv.barrier()
+        elapsed = time.perf_counter() - t0
+        return rdzv.max([elapsed, ev_ms])
+
+    s.poisson_solve(1.0, iters, omega)   # lazy allocations, code objects
+    s.synchronize()
 
     # Clock priming (untimed, reported as `priming_solves`): after set-up (host-side data
     # generation, PCIe uploads) the GPU sits at idle clocks and needs ~30 ms of load to reach its
     # sustained rate (tools/solve_sequence_probe.py: 2.7, 2.5, 2.4 ... 1.93 ms per solve over the
-    # first 15 solves).  A running simulation lives at the sustained rate, so the bench first keeps
-    # the device busy with the same solves for ~80 ms; the W warm-up steps and the K timed steps
-    # follow without a gap.  The count is agreed across ranks (every rank must issue the same
-    # exchanges).
-    priming = 0
+    # first 15 solves).  A running simulation lives at the sustained rate, so `value` is measured
+    # after ~80 ms of the same solves; the same W + K region measured BEFORE them is reported as
+    # `value_unprimed`.  The count is agreed across ranks (every rank issues the same exchanges).
+    priming, unprimed = 0, None
     if not args.no_priming:
-        s.poisson_solve(1.0, iters, omega)   # lazy allocations, code objects
-        sync_all()
-        t_one = time.perf_counter()
-        s.poisson_solve(1.0, iters, omega)
-        sync_all()
-        t_one = time.perf_counter() - t_one
-        if world > 1:
-            tt = torch.tensor([t_one], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_one = float(tt[0])
+        time.sleep(0.05)                 # let the clocks fall back, as after any host-side pause
+        elapsed_cold, _ = timed_region()
+        unprimed = cells * iters * args.steps / elapsed_cold
+        t_one = rdzv.max([elapsed_cold / args.steps])[0]
         # launch-bound tiny grids do not load the GPU at all: nothing to ramp (and hundreds of queued
         # launches only disturb the host-side launch path that bounds them)
         priming = int(min(400, max(4, 0.08 / t_one))) if t_one >= 0.5e-3 else 0
         for _ in range(priming):
             s.poisson_solve(1.0, iters, omega)
-        priming += 2
-    for _ in range(args.warmup):
-        s.poisson_solve(1.0, iters, omega)
-    sync_all()
-    barrier()
-    t0 = time.perf_counter()
-    s.timer_start()
-    for _ in range(args.steps):
-        s.poisson_solve(1.0, iters, omega)
-    ev_ms = s.timer_stop()
-    sync_all()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
 
-    if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(t[0]), float(t[1])
+    # ---- parity of the timed configuration: the p the last timed solve left behind -------------
+    parity, cpu_rec = None, None
+    want_parity = not args.no_cpu_baseline and not (world > 1 and args.no_parity)
+    if want_parity:
+        got = s.download(capi.FIELD_PRESSURE)
+        d_own = s.download(capi.FIELD_DIVERGENCE)
+        if world == 1:
+            want, cpu_rec = cpu_reference_solve(d_own, iters)
+            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+        else:
+            # the ranks assemble the right-hand side in shared memory, rank 0 runs the reference on
+            # the whole domain (the only way to get exact expectations), every rank checks its slab
+            shm = f"/dev/shm/sfl_bench_{os.environ.get('SFL_RDZV_KEY', str(os.getppid()))}"
+            if rank == 0:
+                d_all = np.lib.format.open_memmap(shm + "_d.npy", mode="w+", dtype=np.float32,
+                                                  shape=(dim_y, size))
+            rdzv.barrier()
+            if rank != 0:
+                d_all = np.load(shm + "_d.npy", mmap_mode="r+")
+            d_all[s.row_begin:s.row_end] = d_own
+            d_all.flush()
+            rdzv.barrier()
+            if rank == 0:
+                want_all, _ = cpu_reference_solve(np.ascontiguousarray(d_all), iters, min_seconds=0.0)
+                np.save(shm + "_p.npy", want_all)
+                del want_all
+            rdzv.barrier()
+            want = np.ascontiguousarray(np.load(shm + "_p.npy", mmap_mode="r")[s.row_begin:s.row_end])
+            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+            del d_all
+            bad = int(sum(rdzv.all_gather(bad)))
+            if rank == 0:
+                for suffix in ("_d.npy", "_p.npy"):
+                    try:
+                        os.unlink(shm + suffix)
+                    except OSError:
+                        pass
+        parity = {"config": f"poisson_solve {size}x{dim_y} fp32, {iters} iters, omega 1.96, dx 1, the timed "
+                            f"solve's own output vs the reference CPU loop on the same rhs (poisson.cpp:114-125)",
+                  "bit_exact": bad == 0, "cells": cells, "mismatching_cells": bad,
+                  "tolerance": "1e-5 relative allowed by north_star; asserted 0 ulp"}
 
-    # full sim step, timed separately (not part of `value`).  A slab reports a back-trace that
-    # left its advection halo at synchronize(); every rank still issues the same launches and
-    # exchanges, so the failure is recorded, agreed on collectively and never deadlocks a barrier.
+    # ---- full sim step, timed separately (not part of `value`) ---------------------------------
+    # A slab reports a back-trace that left its advection halo at synchronize(); every rank still
+    # issues the same launches and exchanges, so the failure is recorded, agreed on collectively and
+    # never deadlocks a barrier.
     sim_sps, sim_note = None, None
     if args.sim_steps > 0:
         failed = []
@@ -309,41 +414,69 @@ def main():
         dtf = np.float32(1 / 30.0)
         s.step(dtf, 1.0, iters, omega)
         sync_soft()
-        barrier()
+        rdzv.barrier()
         t1 = time.perf_counter()
         for _ in range(args.sim_steps):
             s.step(dtf, 1.0, iters, omega)
         sync_soft()
-        barrier()
-        sim_t = time.perf_counter() - t1
-        bad = 1.0 if failed else 0.0
-        if world > 1:
-            t = torch.tensor([sim_t, bad], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sim_t, bad = float(t[0]), float(t[1])
-        if bad:
+        rdzv.barrier()
+        sim_t, bad_step = rdzv.max([time.perf_counter() - t1, 1.0 if failed else 0.0])
+        if bad_step:
             sim_note = failed[0] if failed else "a peer rank reported an advection-halo overflow"
         else:
             sim_sps = args.sim_steps / sim_t
 
     op_us = None
     if world == 1 and args.sim_steps > 0:
-        op_us = gpu_operator_times(s, capi, iters)
+        op_us = gpu_operator_times(s, iters, cells)
 
+    rc = 0
     if rank == 0:
-        cells = size * dim_y
         value = cells * iters * args.steps / elapsed
         launches = max(info["launches"], 1)
         # dominant kernel: one launch relaxes every owned cell `fuse`/2 times
         avg_launch_s = (ev_ms / 1e3) / (args.steps * launches)
         bytes_per_launch = SOR_BYTES_PER_CELL_ITER * (cells / world) * iters / launches
-        achieved = bytes_per_launch / avg_launch_s / 1e9
+        algorithmic_gbs = bytes_per_launch / avg_launch_s / 1e9
         name, cus, mem = sfl.device_info(local_rank)
-        lane_cells = s.get_option(capi.OPT_SOR_LANE_CELLS) or 2
-        pmc = pmc_traffic(size, info["fuse"], lane_cells, world) if dim_y == size else None
+        pmc = pmc_record((size, dim_y), info["fuse"], world)
+        # VALU roofline: the reference's 8 individually rounded fp32 operations per relaxation
+        # (poisson.cpp:63-112; contraction to FMA would change results) against the rate at which the
+        # chip issues such operations: 64 lanes x CUs x clock for plain instructions, twice that for
+        # packed ones (v_pk_add_f32 / v_pk_mul_f32 round each half separately).  The kernel's
+        # interior path is packed where the library says so (`packed_fp32` in the solve info).
+        packed = bool(info.get("packed"))
+        valu_peak = cus * 64 * VALU_CLOCK_GHZ / 1e3 * (2 if packed else 1)
+        valu_achieved = value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
+        traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+        roofline = {
+            "bound": "valu", "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
+            "frac": valu_achieved / valu_peak,
+            "peak_definition": f"{cus} CUs x 64 lanes x {VALU_CLOCK_GHZ} GHz x {2 if packed else 1} "
+                               f"({'packed' if packed else 'plain'} fp32 VALU operations, no FMA: the "
+                               "reference rounds every product and sum)",
+            "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
+            "avg_launch_us": avg_launch_s * 1e6,
+            "traffic": traffic,
+            "traffic_source": pmc["source"] if pmc else None,
+            "hbm_traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "issued_over_useful": (pmc["valu_wave_insts_per_launch"] * 64
+                                   / (SOR_FLOPS_PER_CELL_ITER * (cells / world) * iters / launches
+                                      / (2 if packed else 1)))
+            if pmc and pmc.get("valu_wave_insts_per_launch") else None,
+            # SURVEY 8d's figure for an UNFUSED sweep (16 B per cell-iteration); a temporally blocked
+            # kernel moves a fraction of it, so this is a ratio, not a fraction of a roofline
+            "algorithmic": {"bytes_per_cell_iter": SOR_BYTES_PER_CELL_ITER,
+                            "bytes_per_launch": bytes_per_launch, "GBps": algorithmic_gbs,
+                            "hbm_peak_GBps": HBM_PEAK_GBS,
+                            "algorithmic_vs_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
+                            "note": "ratio of unfused-sweep bytes to the HBM peak, > 1 by temporal "
+                                    "blocking; not a roofline fraction"},
+        }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "priming_solves": priming,
+            "value_unprimed": unprimed,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"poisson_solve {size}x{dim_y} fp32, {iters} red-black SOR iters/step, "
@@ -353,29 +486,15 @@ def main():
                        "sor_launches_per_solve": info["launches"],
                        "halo_exchanges_per_solve": info["exchanges"],
                        "half_sweeps_fused_per_launch": info["fuse"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
-                         "traffic_source": pmc["source"] if pmc else None,
-                         "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
-                         "avg_launch_us": avg_launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         # what actually bounds the temporally blocked kernel: the
-                         # reference's 8 unfused fp32 operations per relaxation (poisson.cpp:63-112;
-                         # contraction to FMA would change results) against one plain fp32 VALU
-                         # operation per lane per clock, 64 lanes x CUs x 2.4 GHz
-                         "valu": {"flops_per_cell_iter": SOR_FLOPS_PER_CELL_ITER,
-                                  "achieved": value / world * SOR_FLOPS_PER_CELL_ITER / 1e12,
-                                  "peak": cus * 64 * VALU_CLOCK_GHZ / 1e3, "unit": "TFLOP/s",
-                                  "frac": value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
-                                          / (cus * 64 * VALU_CLOCK_GHZ / 1e3)}},
+            "parity": parity,
+            "roofline": roofline,
             "sim_steps_per_sec": sim_sps,
-            "sim_step_per_operator_us": op_us,
+            "sim_step_per_operator": op_us,
             **({"sim_steps_note": sim_note} if sim_note else {}),
             "device": name,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(size, iters)  # always the square headline grid
+        if cpu_rec:
+            out["cpu_baseline"] = cpu_rec
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
             out["cpu_baseline"]["host_cpu"] = host_cpu_model()
             # the other half of SURVEY 8(d): the reference's per-operator times for one sim step,
@@ -383,12 +502,23 @@ def main():
             out["cpu_baseline"]["sim_step_per_operator"] = [cpu_operator_times(61, 81, 20),
                                                             cpu_operator_times(2048, 2048, 40)]
         print(json.dumps(out), flush=True)
+        if parity and not parity["bit_exact"]:
+            print(f"bench.py: PARITY FAILURE: {parity['mismatching_cells']} cells differ from the "
+                  f"reference", file=sys.stderr)
+            rc = 3
 
-    barrier()
+    rdzv.barrier()
     s.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.close()
+    return rc
+
+
+def main():
+    args = parse_args()
+    in_launcher = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.gpus > 1 and not in_launcher:
+        sys.exit(launch_ranks(args))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -214,16 +214,72 @@ def test_rccl_single_rank_communicator(sfl, oracle):
         assert not got[17:].any()
 
 
+def bench_rhs(sfl, size, dim_y=None):
+    """The right-hand side bench.py solves for: divergence of its seeded velocity field."""
+    import bench
+    dim_y = dim_y or size
+    with sfl.Solver(size, dim_y) as s:
+        s.upload(sfl.capi.FIELD_VELOCITY, bench.synthetic_velocity(size, 0, dim_y))
+        s.calculate_divergence(1.0)
+        s.synchronize()
+        return s.download(sfl.capi.FIELD_DIVERGENCE)
+
+
 def test_headline_size_spot_check_vs_oracle(sfl, oracle):
-    """8192 x 8192 (BASELINE config 3 grid), 4 iterations: the HIP path against the oracle on the
-    full-size grid, every cell, both lane flavours (SURVEY 8d parity gate)."""
-    n = 8192
+    """8192 x 8192 (BASELINE config 3 grid), 16 iterations = 32 colour passes: two launches of the
+    NS = 16 kernel (the second continues from a given p: the instantiation bench.py times), both
+    lane flavours and a shallower depth, every cell against the oracle (SURVEY 8d parity gate)."""
+    n, iters = 8192, 16
     rng = np.random.default_rng(2026)
     d = (rng.standard_normal((n, n)) * 0.05).astype(np.float32)
-    want = oracle.poisson_solve(d, 1.0, 4, OMEGA)
-    for lane, fuse in ((2, 8), (4, 4), (2, 16)):
-        hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_lane_cells=lane)
-        assert_bit_equal(hp.poisson_solve(d, 1.0, 4, OMEGA), want, f"8192^2 lane{lane} fuse{fuse}")
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    for lane, fuse in ((2, 16), (2, 12), (4, 16)):
+        with sfl.Solver(n, n) as s:
+            s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
+            s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            s.set_option(sfl.capi.OPT_SOR_LANE_CELLS, lane)
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+            s.poisson_solve(1.0, iters, OMEGA)
+            s.synchronize()
+            info = s.last_solve_info()
+            got = s.download(sfl.capi.FIELD_PRESSURE)
+        assert info["fuse"] == fuse and info["launches"] == -(-2 * iters // fuse)
+        assert_bit_equal(got, want, f"8192^2 lane{lane} fuse{fuse}")
+
+
+def test_baseline_config3_exactly_as_benchmarked(sfl, oracle):
+    """BASELINE config 3 as bench.py times it: 8192 x 8192, 80 iterations, omega 1.96, dx 1, rhs =
+    divergence of the bench's seeded velocity, EVERY option on auto -- which must resolve to ten
+    launches of the NS = 16 kernel.  Every cell against the oracle (poisson.cpp:114-125; the oracle
+    needs ~10 s on one core).  Tolerance north_star allows: 1e-5 relative; asserted: 0 ulp."""
+    n, iters = 8192, 80
+    d = bench_rhs(sfl, n)
+    with sfl.Solver(n, n) as s:
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        s.poisson_solve(1.0, iters, OMEGA)
+        s.synchronize()
+        info = s.last_solve_info()
+        s.poisson_solve(1.0, iters, OMEGA)      # a second solve on the same context restarts from zero
+        s.synchronize()
+        got = s.download(sfl.capi.FIELD_PRESSURE)
+    assert info["fuse"] == 16 and info["launches"] == 10 and info["exchanges"] == 0
+    assert_bit_equal(got, oracle.poisson_solve(d, 1.0, iters, OMEGA), "C3: 8192^2 x 80 iterations, auto")
+
+
+def test_baseline_config2_vs_oracle(sfl, oracle):
+    """BASELINE config 2: 2048 x 2048, 40 SOR iterations per step, one GPU, every option on auto --
+    the stand-alone solve on the bench's rhs and one whole sim step, every cell of every field."""
+    import bench
+    n, iters = 2048, 40
+    d = bench_rhs(sfl, n)
+    hp = sfl.HostPath()
+    assert_bit_equal(hp.poisson_solve(d, 1.0, iters, OMEGA), oracle.poisson_solve(d, 1.0, iters, OMEGA),
+                     "C2: 2048^2 x 40 iterations, auto")
+    v, c = bench.synthetic_velocity(n, 0, n), bench.synthetic_color(n, 0, n)
+    got = hp.step(v, c, DT, 1.0, iters, OMEGA)
+    want = oracle.step(v, c, DT, 1.0, iters, OMEGA)
+    for name, a, b in zip(("v", "div", "p", "colour"), got, want):
+        assert_bit_equal(a, b, f"C2 step: {name}")
 
 
 def test_large_grid_properties(sfl):

@@ -1,0 +1,38 @@
+"""RCCL with more than one rank: needs >= 2 GPUs in the box (skipped on the 1-GPU test boxes; the
+in-process virtual-rank tests of test_gpu_parity.py cover the same slab program on one GPU).  The
+ranks are fresh processes started by bench.py's own launcher; each solves its slab with RCCL halo
+exchanges and compares the result of the timed solve bit for bit with the reference CPU loop run
+on the whole domain (bench.py's `parity` block); the full sim step runs as well."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices():
+    return importlib.import_module("esp32-fluid-simulation_amd").device_count()
+
+
+@pytest.mark.parametrize("nranks,size,iters,halo", [(2, 2048, 40, 0), (2, 1024, 24, 16), (4, 2048, 40, 0), (8, 4096, 30, 0)])
+def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo):
+    if _devices() < nranks:
+        pytest.skip(f"needs {nranks} GPUs, {_devices()} visible")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--size", str(size),
+           "--iters", str(iters), "--steps", "2", "--warmup", "1", "--sim-steps", "1"]
+    if halo:
+        cmd += ["--sor-halo", str(halo)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == nranks
+    assert out["parity"]["bit_exact"] and out["parity"]["cells"] == size * size
+    assert out["config"]["halo_exchanges_per_solve"] > 0
+    assert out["sim_steps_per_sec"] is not None, out.get("sim_steps_note")

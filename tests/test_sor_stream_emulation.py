@@ -60,7 +60,7 @@ def test_fused_passes_from_zero(emu, oracle, dim_x, dim_y, ns):
 
 
 @pytest.mark.parametrize("dim_x,dim_y", SHAPES)
-@pytest.mark.parametrize("ns", [2, 8, 10, 14])
+@pytest.mark.parametrize("ns", [2, 8, 10, 12, 14, 16])
 def test_fused_passes_continue(emu, oracle, dim_x, dim_y, ns):
     rng = np.random.default_rng(7)
     d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
