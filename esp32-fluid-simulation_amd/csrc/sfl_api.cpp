@@ -99,6 +99,24 @@ struct sfl_context {
     int *d_force_cells = nullptr;
     float *d_force_vel = nullptr;
     int d_force_cap = 0;
+    // pinned staging of the queued forces, two slots used alternately: the copy of step k may
+    // still be in flight while step k + 1 is being queued, never the one of step k - 1 (each
+    // slot's last copy is fenced by its event before the slot is rewritten)
+    struct ForceStage {
+        int *cells = nullptr;
+        float *vel = nullptr;
+        int cap = 0;
+        hipEvent_t copied = nullptr;
+        bool pending = false;
+    } force_stage[2];
+    int force_slot = 0;
+
+    // dye visualiser: device image + pinned host staging, kept between frames
+    uint16_t *d_image = nullptr;
+    size_t d_image_bytes = 0;
+
+    // scratch field of sfl_host_advect_vec2f when the advected field is not the velocity
+    float *host_scratch = nullptr;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1;
@@ -354,6 +372,19 @@ int check_dims(int dim_x, int dim_y)
     return SFL_OK;
 }
 
+// The kernels address a context's LOCAL arrays (owned + ghost rows) with 32-bit signed byte
+// offsets; the widest element they index that way is the 8-byte velocity, so a local array may
+// hold at most 2^28 cells (= 16384 x 16384, BASELINE config 5 on one GPU: 2 GiB of velocity).
+// Larger domains need more slabs.
+constexpr int64_t kMaxLocalCells = (int64_t)1 << 28;
+int check_local_cells(int dim_x, int lrows)
+{
+    if ((int64_t)dim_x * lrows > kMaxLocalCells)
+        return fail(SFL_ERR_INVALID, "a context holds at most 2^28 cells (%d x %d local rows asked): "
+                    "split the domain into more slabs", dim_x, lrows);
+    return SFL_OK;
+}
+
 int default_device()
 {
     const char *e = getenv("SFL_DEVICE");
@@ -513,6 +544,11 @@ int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int ran
     if (nranks < 1 || rank < 0 || rank >= nranks)
         return fail(SFL_ERR_INVALID, "bad rank %d of %d", rank, nranks);
     if (nranks > dim_y) return fail(SFL_ERR_INVALID, "more slabs (%d) than rows (%d)", nranks, dim_y);
+    {
+        int b = 0, e = 0;
+        sfl::slab_rows(dim_y, nranks, rank, &b, &e);
+        SFL_TRY(check_local_cells(dim_x, (e - b) + (nranks > 1 ? 2 * kGhostRows : 0)));
+    }
     int ndev = 0;
     SFL_TRY(sfl_device_count(&ndev));
     if (device < 0 || device >= ndev)
@@ -563,8 +599,14 @@ int sfl_destroy(sfl_context *c)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
                     (void *)c->div, (void *)c->p, (void *)c->p_alt, (void *)c->halo_flag,
-                    (void *)c->d_force_cells, (void *)c->d_force_vel})
+                    (void *)c->d_force_cells, (void *)c->d_force_vel, (void *)c->d_image,
+                    (void *)c->host_scratch})
         if (m) (void)hipFree(m);
+    for (auto &st : c->force_stage) {
+        if (st.cells) (void)hipHostFree(st.cells);
+        if (st.vel) (void)hipHostFree(st.vel);
+        if (st.copied) (void)hipEventDestroy(st.copied);
+    }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -572,9 +614,8 @@ int sfl_destroy(sfl_context *c)
     return SFL_OK;
 }
 
-int sfl_set_option(sfl_context *c, int option, int value)
+static int set_option_one(sfl_context *c, int option, int value)
 {
-    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
     switch (option) {
         case SFL_OPT_SOR_KERNEL:
             if (value < 0 || value > 2) return fail(SFL_ERR_INVALID, "SOR kernel must be 0, 1 or 2");
@@ -611,6 +652,16 @@ int sfl_set_option(sfl_context *c, int option, int value)
             return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
+}
+
+// Options of a linked group are GROUP-wide: the slabs execute one program in lock step, and a
+// halo a peer trusts must be the halo that was exchanged (sfl_group_link aligns the members with
+// slab 0 to begin with).  With RCCL every rank is its own process: set the same options on all.
+int sfl_set_option(sfl_context *ctx, int option, int value)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    for (sfl_context *c : peers_of(ctx)) SFL_TRY(set_option_one(c, option, value));
+    return SFL_OK;
 }
 
 int sfl_get_option(sfl_context *c, int option, int *value)
@@ -689,6 +740,16 @@ int sfl_group_link(sfl_context **ctxs, int n)
     g->members.assign(ctxs, ctxs + n);
     HIP_TRY(hipSetDevice(ctxs[0]->device));
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    for (int r = 1; r < n; ++r) {  // group-wide options: slab 0's values
+        sfl_context *c = ctxs[r], *z = ctxs[0];
+        c->opt_sor_kernel = z->opt_sor_kernel;
+        c->opt_sor_fuse = z->opt_sor_fuse;
+        c->opt_advect_halo = z->opt_advect_halo;
+        c->opt_sor_rows = z->opt_sor_rows;
+        c->opt_sor_lane_cells = z->opt_sor_lane_cells;
+        c->opt_sor_halo = z->opt_sor_halo;
+        c->opt_fuse_projection = z->opt_fuse_projection;
+    }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
         (void)hipStreamSynchronize(c->stream);
@@ -832,26 +893,54 @@ static int apply_queued_forces(sfl_context *c)
     if (n == 0) return SFL_OK;
     SFL_TRY(use_device(c));
     if (n > c->d_force_cap) {
+        // the previous step's kernel may still read the old arrays: drain once, on growth only
+        HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_force_cells) (void)hipFree(c->d_force_cells);
         if (c->d_force_vel) (void)hipFree(c->d_force_vel);
         c->d_force_cells = nullptr;
         c->d_force_vel = nullptr;
+        c->d_force_cap = 0;
         void *a = nullptr, *b = nullptr;
         HIP_TRY(hipMalloc(&a, sizeof(int) * 2 * n));
-        HIP_TRY(hipMalloc(&b, sizeof(float) * 2 * n));
         c->d_force_cells = static_cast<int *>(a);
+        HIP_TRY(hipMalloc(&b, sizeof(float) * 2 * n));
         c->d_force_vel = static_cast<float *>(b);
         c->d_force_cap = n;
     }
-    HIP_TRY(hipMemcpyAsync(c->d_force_cells, c->force_cells.data(), sizeof(int) * 2 * n,
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_force_vel, c->force_vel.data(), sizeof(float) * 2 * n,
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
-                                     c->d_force_vel, n));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors are about to be cleared
+    // stage in pinned memory so that the copies are truly asynchronous and the host vectors can be
+    // cleared at once; a slot is reused every second step, after its own copy has completed
+    sfl_context::ForceStage &st = c->force_stage[c->force_slot];
+    c->force_slot ^= 1;
+    if (!st.copied) HIP_TRY(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+    if (st.pending) {
+        HIP_TRY(hipEventSynchronize(st.copied));
+        st.pending = false;
+    }
+    if (n > st.cap) {
+        if (st.cells) (void)hipHostFree(st.cells);
+        if (st.vel) (void)hipHostFree(st.vel);
+        st.cells = nullptr;
+        st.vel = nullptr;
+        st.cap = 0;
+        void *a = nullptr, *b = nullptr;
+        HIP_TRY(hipHostMalloc(&a, sizeof(int) * 2 * n, hipHostMallocDefault));
+        st.cells = static_cast<int *>(a);
+        HIP_TRY(hipHostMalloc(&b, sizeof(float) * 2 * n, hipHostMallocDefault));
+        st.vel = static_cast<float *>(b);
+        st.cap = n;
+    }
+    memcpy(st.cells, c->force_cells.data(), sizeof(int) * 2 * n);
+    memcpy(st.vel, c->force_vel.data(), sizeof(float) * 2 * n);
     c->force_cells.clear();
     c->force_vel.clear();
+    HIP_TRY(hipMemcpyAsync(c->d_force_cells, st.cells, sizeof(int) * 2 * n, hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_force_vel, st.vel, sizeof(float) * 2 * n, hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipEventRecord(st.copied, c->stream));
+    st.pending = true;
+    HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
+                                     c->d_force_vel, n));
     return SFL_OK;
 }
 
@@ -915,14 +1004,22 @@ int sfl_render_rgb565(sfl_context *c, int scaling, int byteswap, uint16_t *host_
     if (bytes != w * h * 2) return fail(SFL_ERR_INVALID, "image is %zu x %zu uint16 = %zu bytes, got %zu", h, w, w * h * 2, bytes);
     SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
     SFL_TRY(use_device(c));
-    void *img = nullptr;
-    HIP_TRY(hipMalloc(&img, bytes));
-    hipError_t e = sfl::launch_render_rgb565(c->stream, static_cast<uint16_t *>(img), c->col, c->dim_x,
-                                             c->gdim_y, scaling, byteswap != 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(host_image, img, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(img);
-    if (e != hipSuccess) return fail(SFL_ERR_HIP, "render failed: %s", hipGetErrorString(e));
+    if (bytes > c->d_image_bytes) {  // the frame buffer stays with the context between frames
+        if (c->d_image) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_image);
+            c->d_image = nullptr;
+            c->d_image_bytes = 0;
+        }
+        void *img = nullptr;
+        HIP_TRY(hipMalloc(&img, bytes));
+        c->d_image = static_cast<uint16_t *>(img);
+        c->d_image_bytes = bytes;
+    }
+    HIP_TRY(sfl::launch_render_rgb565(c->stream, c->d_image, c->col, c->dim_x, c->gdim_y, scaling,
+                                      byteswap != 0));
+    HIP_TRY(hipMemcpyAsync(host_image, c->d_image, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller reads host_image on return
     return SFL_OK;
 }
 
@@ -988,17 +1085,15 @@ int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int d
     SFL_TRY(ensure(c, c->vel_tmp, 8, false));
     SFL_TRY(upload_raw(c, c->vel, vel, 8));
     float *src = c->vel;
-    float *other = nullptr;
-    if (p != vel) {  // advected field differs from the velocity
-        SFL_TRY(ensure(c, other, 8, false));
-        SFL_TRY(upload_raw(c, other, p, 8));
-        src = other;
+    if (p != vel) {  // advected field differs from the velocity: scratch field kept with the context
+        SFL_TRY(ensure(c, c->host_scratch, 8, false));
+        SFL_TRY(upload_raw(c, c->host_scratch, p, 8));
+        src = c->host_scratch;
     }
     hipError_t e = sfl::launch_advect_vec2f(c->stream, c->vel_tmp, src, c->vel, c->geom, 0, dim_y, 0,
                                             dim_y, dt, no_slip != 0, nullptr);
     int rc = e == hipSuccess ? download_raw(c, c->vel_tmp, next_p, 8)
                              : fail(SFL_ERR_HIP, "advect launch failed: %s", hipGetErrorString(e));
-    if (other) (void)hipFree(other);
     return t.done(rc);
 }
 

@@ -165,6 +165,9 @@ SFL_API int sfl_host_release(void);
 
 /* Whole domain on one device (rank 0 of 1). */
 SFL_API int sfl_create(sfl_context **out, int device, int dim_x, int dim_y);
+/* Limits: dim_x, dim_y >= 2; at most 2^30 cells per domain and 2^28 cells (owned + 128 ghost rows
+ * on a slab) per context -- the kernels address a context's arrays with 32-bit byte offsets;
+ * larger domains need more slabs.  Violations return SFL_ERR_INVALID before any GPU is touched.  */
 /* Row slab `rank` of `nranks` (sfl_slab_rows) of a dim_x * dim_y domain on `device`.
  * Neighbouring slabs exchange halos through RCCL once sfl_comm_attach() has run, or through
  * in-process copies when the contexts were joined with sfl_group_link().                    */
@@ -172,6 +175,8 @@ SFL_API int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y,
                             int nranks);
 SFL_API int sfl_destroy(sfl_context *ctx);
 
+/* Options of contexts joined by sfl_group_link are group-wide (setting one member sets all; linking
+ * aligns the members with slab 0).  RCCL ranks are separate processes: set the same values on each. */
 SFL_API int sfl_set_option(sfl_context *ctx, int option, int value);
 SFL_API int sfl_get_option(sfl_context *ctx, int option, int *value);
 
@@ -195,8 +200,12 @@ SFL_API int sfl_group_link(sfl_context **ctxs, int n);
  *     `host` holds (row_end-row_begin) * dim_x elements of the field's element type.       */
 SFL_API int sfl_upload(sfl_context *ctx, int field, const void *host, size_t bytes);
 SFL_API int sfl_download(sfl_context *ctx, int field, void *host, size_t bytes);
-/* Device pointer of the first OWNED row (for zero-copy interop, e.g. torch tensors made
- * with from_blob; the context keeps ownership).                                           */
+/* Device pointer of the first OWNED row of the field's CURRENT buffer (zero-copy interop; the
+ * context keeps ownership).  Velocity, colour and pressure are ping-ponged between two buffers by
+ * the operators that rewrite them (advect: ino:255,286; the fused SOR launches), so the pointer
+ * is valid only until the next operator that writes that field -- sfl_step writes all of them:
+ * query again after every such call (the query costs nothing).  Asynchronous work may still be
+ * pending: sfl_synchronize() before reading through the pointer from another stream.           */
 SFL_API int sfl_field_device_ptr(sfl_context *ctx, int field, void **dev_ptr);
 
 /* --- operators on the resident fields, asynchronous on the context's stream.

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "sfl.h"
 
 #define CHECK(call)                                                              \
@@ -54,6 +56,26 @@ int main(int argc, char **argv)
     CHECK(sfl_download(sim, SFL_FIELD_VELOCITY, vel.data(), 8 * n));
     CHECK(sfl_download(sim, SFL_FIELD_PRESSURE, p.data(), 4 * n));
     CHECK(sfl_download(sim, SFL_FIELD_COLOR, col.data(), 12 * n));
+    // zero-copy view (sfl_field_device_ptr): queried AFTER the last operator, it must show exactly
+    // what sfl_download returns -- the operators ping-pong their buffers, so a pointer is only good
+    // until the next operator that writes the field (include/sfl.h)
+    {
+        void *dv = nullptr, *dp = nullptr, *dc = nullptr;
+        CHECK(sfl_field_device_ptr(sim, SFL_FIELD_VELOCITY, &dv));
+        CHECK(sfl_field_device_ptr(sim, SFL_FIELD_PRESSURE, &dp));
+        CHECK(sfl_field_device_ptr(sim, SFL_FIELD_COLOR, &dc));
+        std::vector<float> v2(2 * n), p2(n);
+        std::vector<uint32_t> c2(3 * n);
+        if (hipMemcpy(v2.data(), dv, 8 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(p2.data(), dp, 4 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(c2.data(), dc, 12 * n, hipMemcpyDeviceToHost) != hipSuccess)
+            return 7;
+        if (std::memcmp(v2.data(), vel.data(), 8 * n) || std::memcmp(p2.data(), p.data(), 4 * n) ||
+            std::memcmp(c2.data(), col.data(), 12 * n)) {
+            std::fprintf(stderr, "sfl_field_device_ptr does not show the current field contents\n");
+            return 8;
+        }
+    }
     CHECK(sfl_destroy(sim));
 
     FILE *out = std::fopen(argv[3], "wb");

@@ -87,3 +87,26 @@ def test_poisson_program_shape(sfl):
     prog = sfl.plan_poisson(100, 2, 1, 2, 8, 1)
     assert [s.kind for s in prog] == [Z, S, E, S, E, S, E, S]
     assert [s.first_colour for s in prog if s.kind == S] == [0, 1, 0, 1]
+
+
+def test_context_size_limits_are_rejected_before_any_gpu_is_touched(sfl):
+    """The kernels address a context's local arrays with 32-bit byte offsets (8-byte velocity
+    elements): a context may hold at most 2^28 cells, a domain 2^30; both limits come back as
+    SFL_ERR_INVALID -- on a box without a GPU too, i.e. before the device is even looked at."""
+    import ctypes as C
+    lib, cap = sfl.capi.lib(), sfl.capi
+    h = C.c_void_p()
+    for dim_x, dim_y, rank, nranks, code in [
+            (32768, 16384, 0, 1, cap.ERR_INVALID),     # 2^29 cells in one context
+            (16384, 16385, 0, 1, cap.ERR_INVALID),     # one row too many
+            (65536, 32768, 0, 8, cap.ERR_INVALID),     # domain beyond 2^30 cells
+            (16384, 32768, 0, 2, cap.ERR_INVALID),     # slab of 2^28 cells + ghost rows
+            (1, 8, 0, 1, cap.ERR_INVALID), (8, 1, 0, 1, cap.ERR_INVALID)]:
+        rc = lib.sfl_create_slab(C.byref(h), 0, dim_x, dim_y, rank, nranks)
+        assert rc == code, (dim_x, dim_y, rank, nranks, rc, lib.sfl_last_error())
+        assert not h.value
+    # within the limits the only possible failure is the missing device
+    rc = lib.sfl_create_slab(C.byref(h), 0, 16384, 32768, 1, 4)
+    assert rc in (cap.OK, cap.ERR_HIP)
+    if rc == cap.OK:
+        lib.sfl_destroy(h)

@@ -152,3 +152,28 @@ def test_c_abi_context_loop_with_forces(tmp_path, oracle):
         c = oracle.advect_vec3uq32(c, v, dt, False)
     for name, a, b in (("v", got_v, v), ("p", got_p, p), ("colour", got_c, c)):
         assert_bit_equal(a, b, f"C-ABI context loop: {name}")
+
+
+def _header_goldens():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_header_goldens",
+                                                  os.path.join(ROOT, "tests", "golden", "make_header_goldens.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("driver,fixture", [("domain_iter_driver.cpp", "domain_iter_reference.txt"),
+                                            ("sample_driver.cpp", "sample_reference.txt")])
+def test_header_templates_executed_against_reference_bits(driver, fixture):
+    """`domain_iter` (operations.h:11-38; in place with order-sensitive expressions,
+    wrt == rd, and T != U) and the per-point helpers lerp / billinear_interpolate / sample
+    (advect.h:10-72) are EXECUTED from include/sfl and must leave exactly the bits the reference's
+    own headers leave (fixture generated from /root/reference by tests/golden/make_header_goldens.py;
+    where the reference is present the comparison is also made live)."""
+    m = _header_goldens()
+    ours = m.run_driver(os.path.join(INC, "sfl"), driver)
+    want = open(os.path.join(ROOT, "tests", "golden", fixture)).read()
+    assert ours == want
+    if os.path.isdir(m.REF):
+        assert m.run_driver(m.REF, driver) == want

@@ -591,3 +591,29 @@ def test_host_dropins_keep_a_working_context_per_thread(sfl, oracle):
     assert lib.sfl_host_calculate_divergence(fp(d), fp(v), dim_x, dim_y, C.c_float(1.0)) == 0
     assert_bit_equal(d, oracle.divergence(v, 1.0), "after release")
     assert lib.sfl_host_release() == 0
+
+
+def test_group_options_are_group_wide(sfl, oracle):
+    """Options of linked slabs are one set: a value given to ANY member (before or after linking) is
+    what every member exchanges and trusts -- a peer can never rely on ghost rows nobody sent."""
+    dim_x, dim_y, nranks = 64, 120, 3
+    v = np.zeros((dim_y, dim_x, 2), np.float32)
+    v[..., 1] = 30.0 * 9          # back-trace of 9 rows: beyond the default 4-row advection halo
+    v[..., 0] = 7.0
+    want = oracle.advect_vec2f(v, v, DT, True)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 6)      # before linking: slab 0's values win
+        sfl.Solver.link_group(slabs)
+        slabs[2].set_option(sfl.capi.OPT_ADVECT_HALO, 12)  # after linking: any member sets all
+        for s in slabs:
+            assert s.get_option(sfl.capi.OPT_ADVECT_HALO) == 12
+            assert s.get_option(sfl.capi.OPT_SOR_FUSE) == 6
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+        slabs[1].advect_velocity(DT, True)
+        slabs[1].synchronize()                              # no SFL_ERR_HALO
+        got = np.concatenate([s.download(sfl.capi.FIELD_VELOCITY) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert_bit_equal(got, want, "advection with a group-wide 12-row halo")
