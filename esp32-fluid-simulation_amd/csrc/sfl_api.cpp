@@ -89,6 +89,9 @@ struct sfl_context {
     // fields: local arrays of geom.lrows rows (allocated on first use)
     float *vel = nullptr, *vel_tmp = nullptr;
     uint32_t *col = nullptr, *col_tmp = nullptr;
+    // div, p and p_alt are three thirds of ONE allocation (sor_block): the twin-tile SOR kernel
+    // addresses all three through a single buffer resource (they must lie within 4 GiB)
+    float *sor_block = nullptr;
     float *div = nullptr;
     float *p = nullptr, *p_alt = nullptr;  // p = current pressure, p_alt = ping-pong partner
     int *halo_flag = nullptr;
@@ -125,7 +128,7 @@ struct sfl_context {
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
 
-    int last_launches = 0, last_exchanges = 0, last_fuse = 0;
+    int last_launches = 0, last_exchanges = 0, last_fuse = 0, last_lane_cells = 0;
 
     size_t local_cells() const { return (size_t)geom.lrows * dim_x; }
     size_t owned_offset_cells() const { return (size_t)ghost * dim_x; }
@@ -159,13 +162,29 @@ int ensure(sfl_context *c, T *&ptr, size_t elem_bytes, bool zero)
     return SFL_OK;
 }
 
+// divergence, pressure and the pressure's ping-pong partner: one block, zero-filled
+int ensure_sor_block(sfl_context *c)
+{
+    if (c->sor_block) return SFL_OK;
+    SFL_TRY(use_device(c));
+    const size_t cells = (c->local_cells() + 63) & ~(size_t)63;  // thirds stay 256-byte aligned
+    void *m = nullptr;
+    HIP_TRY(hipMalloc(&m, 3 * cells * 4));
+    HIP_TRY(hipMemsetAsync(m, 0, 3 * cells * 4, c->stream));
+    c->sor_block = static_cast<float *>(m);
+    c->div = c->sor_block;
+    c->p = c->sor_block + cells;
+    c->p_alt = c->sor_block + 2 * cells;
+    return SFL_OK;
+}
+
 int ensure_field(sfl_context *c, int field)
 {
     switch (field) {
         case SFL_FIELD_VELOCITY: return ensure(c, c->vel, 8, true);
         case SFL_FIELD_COLOR: return ensure(c, c->col, 12, true);
-        case SFL_FIELD_DIVERGENCE: return ensure(c, c->div, 4, true);
-        case SFL_FIELD_PRESSURE: return ensure(c, c->p, 4, true);
+        case SFL_FIELD_DIVERGENCE:
+        case SFL_FIELD_PRESSURE: return ensure_sor_block(c);
     }
     return fail(SFL_ERR_INVALID, "unknown field id %d", field);
 }
@@ -319,10 +338,9 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
         ++c->last_launches;
         return SFL_OK;
     }
-    SFL_TRY(ensure(c, c->p_alt, 4, false));
     HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
                                   c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
-                                  c->opt_sor_rows, c->opt_sor_lane_cells));
+                                  c->opt_sor_rows, c->opt_sor_lane_cells, &c->last_lane_cells));
     std::swap(c->p, c->p_alt);
     ++c->last_launches;
     return SFL_OK;
@@ -341,6 +359,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
                                           effective_halo(ctx, fuse)));
         c->last_launches = c->last_exchanges = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
+        c->last_lane_cells = 0;
     }
     const sfl::SorParams prm = sor_params(dx, omega);
     if (iters == 0) {  // the reference still zero-fills p (poisson.cpp:117-119)
@@ -598,7 +617,7 @@ int sfl_destroy(sfl_context *c)
     c->keepalive.reset();
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
-                    (void *)c->div, (void *)c->p, (void *)c->p_alt, (void *)c->halo_flag,
+                    (void *)c->sor_block, (void *)c->halo_flag,
                     (void *)c->d_force_cells, (void *)c->d_force_vel, (void *)c->d_image,
                     (void *)c->host_scratch})
         if (m) (void)hipFree(m);
@@ -637,6 +656,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             return SFL_OK;
         case SFL_OPT_TRANSPORT:
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
+        case SFL_OPT_SOR_LANE_CELLS_USED:
+            return fail(SFL_ERR_INVALID, "SFL_OPT_SOR_LANE_CELLS_USED is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
@@ -646,8 +667,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_sor_halo = value;
             return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS:
-            if (value != 0 && value != 2 && value != 4)
-                return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto), 2 or 4");
+            if (value != 0 && value != 2 && value != 4 && value != SFL_LANE_CELLS_TWIN)
+                return fail(SFL_ERR_INVALID, "tile flavour must be 0 (auto), 2, 4 or %d (twin)", SFL_LANE_CELLS_TWIN);
             c->opt_sor_lane_cells = value;
             return SFL_OK;
     }
@@ -676,6 +697,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
+        case SFL_OPT_SOR_LANE_CELLS_USED: *value = c->last_lane_cells; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }

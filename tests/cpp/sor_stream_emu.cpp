@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "sor_stream_core.h"
-#include "sor_stream_pairs.h"
 
 namespace {
 
@@ -41,18 +40,19 @@ EMU_BINOP(-)
 EMU_BINOP(*)
 #undef EMU_BINOP
 
-// a pair of rows (sor_stream_pairs.h): both halves 64 lanes wide
+// value type of the twin backend: {tile A, tile B}, both halves 64 lanes wide
 struct V64x2 {
     V64 x, y;
 };
 inline V64x2 operator+(const V64x2 &a, const V64x2 &b) { return {a.x + b.x, a.y + b.y}; }
 inline V64x2 operator-(const V64x2 &a, const V64x2 &b) { return {a.x - b.x, a.y - b.y}; }
+inline V64x2 operator*(const V64x2 &a, const V64x2 &b) { return {a.x * b.x, a.y * b.y}; }
 
 struct EmuBackend {
     using V = V64;
     using M = M64;
-    using V2 = V64x2;
-    static constexpr int kPrefetch = 6;
+    static constexpr int kPrefetch = 6, kRingAlign = 6;
+    static constexpr bool kRingInRegs = false;
 
     const float *p_in;
     const float *d;
@@ -99,6 +99,8 @@ struct EmuBackend {
         for (int i = 0; i < 63; ++i) r.l[i] = x.l[i + 1];
         return r;
     }
+    V add_from_lower(const V &x) const { return from_lower_lane(x) + x; }
+    V add_from_upper(const V &x) const { return x + from_upper_lane(x); }
     sfl::sor::RowFacts row_facts(int r) const
     {
         return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
@@ -160,24 +162,47 @@ struct EmuBackend {
         return r;
     }
     V detach(const V &x) const { return x; }
-    V2 make2(const V &lo, const V &hi) const { return {lo, hi}; }
-    V lo(const V2 &p) const { return p.x; }
-    V hi(const V2 &p) const { return p.y; }
-    V2 scale2(float s, const V2 &v) const
+};
+
+// The twin backend of the product (sor_fused.hip: Twin2) in emulation: V = {tile A, tile B}, tile B
+// = the same columns `delta` rows further up, the right-hand side ring in pipeline registers.
+struct EmuTwin {
+    using V = V64x2;
+    using M = bool;
+    static constexpr int kPrefetch = EMU_TWIN_PREFETCH;
+    static constexpr int kRingAlign = (kPrefetch % 2 == 0) ? kPrefetch : 2 * kPrefetch;
+    static constexpr bool kRingInRegs = true;
+
+    EmuBackend a;   // memory access of tile A; tile B shifts the rows
+    int delta;
+
+    V splat(float x) const { return {a.splat(x), a.splat(x)}; }
+    V select(M m, const V &p, const V &q) const { return m ? p : q; }
+    M mask_and(M m, bool row) const { return m && row; }
+    V from_lower_lane(const V &v) const { return {a.from_lower_lane(v.x), a.from_lower_lane(v.y)}; }
+    V from_upper_lane(const V &v) const { return {a.from_upper_lane(v.x), a.from_upper_lane(v.y)}; }
+    V add_from_lower(const V &v) const { return {a.add_from_lower(v.x), a.add_from_lower(v.y)}; }
+    V add_from_upper(const V &v) const { return {a.add_from_upper(v.x), a.add_from_upper(v.y)}; }
+    sfl::sor::RowFacts row_facts(int r) const { return a.row_facts(r); }
+    template <class P>
+    void poison(P &pp) const { a.poison(pp); }
+    V detach(const V &v) const { return v; }
+    void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
-        V2 r;
-        for (int i = 0; i < 64; ++i) {
-            r.x.l[i] = s * v.x.l[i];
-            r.y.l[i] = s * v.y.l[i];
-        }
-        return r;
+        a.load_row(r, pa.x, pb.x, da.x, db.x);
+        a.load_row(r + delta, pa.y, pb.y, da.y, db.y);
     }
-    V2 from_lower_lane2(const V2 &p) const { return {from_lower_lane(p.x), from_lower_lane(p.y)}; }
-    V2 from_upper_lane2(const V2 &p) const { return {from_upper_lane(p.x), from_upper_lane(p.y)}; }
-    V2 ring_load2(int slot_lo, int slot_hi, int plane) const
+    void store_row(int r, const V &p, const V &q)
     {
-        return {ring_load(slot_lo, plane), ring_load(slot_hi, plane)};
+        a.store_row(r, p.x, q.x);
+        a.tile_r0 += delta;
+        a.tile_r1 += delta;
+        a.store_row(r + delta, p.y, q.y);
+        a.tile_r0 -= delta;
+        a.tile_r1 -= delta;
     }
+    void ring_store(int, int, const V &) {}
+    V ring_load(int, int) const { return V{}; }
 };
 
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
@@ -198,11 +223,12 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge, bool balance, bool pairs)
+               bool vec2, bool poison, bool force_edge, bool balance, bool twin)
 {
     using namespace sfl::sor;
+    constexpr int twin_ring = ring_rows(NS, EmuTwin::kRingAlign);
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance ? kEdgeRowCost16 : 0);
+                                 balance ? kEdgeRowCost16 : 0, twin, twin ? twin_ring : 0);
     int stray = 0;
     {
         for (int tile = 0; tile < t.n_tiles; ++tile) {
@@ -222,25 +248,28 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.out_hi = bk.x0 + t.tile_cols - t.halo_cols;
             bk.vec2 = vec2;
             bk.poison_on = poison;
-            bk.ring.assign((size_t)(pairs_supported(NS) ? pair_ring_rows(NS) : ring_rows(NS)) * 2 * 64,
-                           poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
+            bk.ring.assign((size_t)ring_rows(NS) * 2 * 64, poison ? std::numeric_limits<float>::quiet_NaN() : 0.0f);
             const int r0 = rect.r0, r1 = rect.r1;
             bk.tile_r0 = r0;
             bk.tile_r1 = r1;
             bk.stray_stores = &stray;
             Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
-            const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
+            // a twin kernel sends every tile that is not a twin tile down the boundary path
+            const bool edge = force_edge || twin || tile_touches_boundary(t, rect, gdim_y);
             const bool dx1 = dx == 1.0f;
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
 #define EMU_RUN(EDGE, DX1, ZERO) stream_tile<EmuBackend, NS, EDGE, DX1, ZERO>(bk, c, eca, ecb, r0, r1)
-#define EMU_RUN_PAIRS(DX1, ZERO) stream_tile_pairs<EmuBackend, NS, DX1, ZERO>(bk, dx, omega, 1.0f - omega, r0, r1)
-            if constexpr (pairs_supported(NS)) {
-                if (pairs && !edge) {  // interior tiles: the stage-paired pipeline
-                    if (dx1) { if (zero_in) EMU_RUN_PAIRS(true, true); else EMU_RUN_PAIRS(true, false); }
-                    else     { if (zero_in) EMU_RUN_PAIRS(false, true); else EMU_RUN_PAIRS(false, false); }
-                    continue;
-                }
+            if (rect.twin) {  // the product's twin backend: rows [r0, r1) and [r0 + delta, r1 + delta)
+                if (tile_touches_boundary(t, rect, gdim_y)) return -1000;  // never, by construction
+                EmuTwin tw{bk, rect.delta};
+                Consts<EmuTwin> ct{tw.splat(dx), tw.splat(omega), tw.splat(1.0f - omega)};
+                const EdgeCell<EmuTwin> none{};
+#define EMU_RUN_TWIN(DX1, ZERO) stream_tile<EmuTwin, NS, false, DX1, ZERO>(tw, ct, none, none, r0, r1)
+                if (dx1) { if (zero_in) EMU_RUN_TWIN(true, true); else EMU_RUN_TWIN(true, false); }
+                else     { if (zero_in) EMU_RUN_TWIN(false, true); else EMU_RUN_TWIN(false, false); }
+#undef EMU_RUN_TWIN
+                continue;
             }
             if (edge) {
                 if (dx1) { if (zero_in) EMU_RUN(true, true, true); else EMU_RUN(true, true, false); }
@@ -250,7 +279,6 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
                 else     { if (zero_in) EMU_RUN(false, false, true); else EMU_RUN(false, false, false); }
             }
 #undef EMU_RUN
-#undef EMU_RUN_PAIRS
         }
     }
     return stray;
@@ -265,13 +293,13 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
-                 bool vec2, bool poison, bool force_edge, bool balance, bool pairs
+                 bool vec2, bool poison, bool force_edge, bool balance, bool twin
 #define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
 #define EMU_DEFINE(N)                                                                             \
     int emu_run_ns##N(EMU_ARGS)                                                                   \
     {                                                                                             \
         return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                            rows_per_chunk, vec2, poison, force_edge, balance, pairs);            \
+                            rows_per_chunk, vec2, poison, force_edge, balance, twin);             \
     }
 EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
 EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
@@ -291,19 +319,19 @@ EMU_DEFINE(16)
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
 //        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
-//        bit4 = interior tiles run the stage-paired pipeline (sor_stream_pairs.h)
+//        bit4 = twin tiling: the middle rows of the inner strips run the twin backend
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
               int lrows, int g_begin, int g_end, int ns, float dx, float omega,
               int rows_per_chunk, int flags)
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
-    const bool pairs = flags & 16;
-    if (vec2 && (dim_x & 1)) return -1;
+    const bool twin = flags & 16;
+    if ((vec2 || twin) && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
         return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
-                             omega, rows_per_chunk, vec2, poison, force_edge, balance, pairs) ? -3 : 0;
+                             omega, rows_per_chunk, vec2 || twin, poison, force_edge, balance, twin) ? -3 : 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)
@@ -319,21 +347,25 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 // of rows [g_begin, g_end) and 0 elsewhere.
 extern "C" __attribute__((visibility("default"))) int
 emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin, int g_end,
-                 int rows_per_chunk, int balance, int *cover, int *n_edge)
+                 int rows_per_chunk, int balance, int twin, int *cover, int *n_edge)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance);
+                                 balance, twin, twin ? ring_rows(ns, 6) : 0);
     *n_edge = 0;
     for (int tile = 0; tile < t.n_tiles; ++tile) {
         const TileRect r = tile_rect(t, tile);
         if (r.strip < 0 || r.strip >= t.n_strips || r.r0 >= r.r1) return -1;
-        if (tile_touches_boundary(t, r, gdim_y)) ++*n_edge;
+        if (tile_touches_boundary(t, r, gdim_y)) {
+            if (r.twin) return -2;  // twin tiles are interior tiles by construction
+            ++*n_edge;
+        }
         const int x0 = strip_x0(t, r.strip);
         const int lo = x0 + t.halo_cols, hi = x0 + t.tile_cols - t.halo_cols;
-        for (int y = r.r0; y < r.r1; ++y)
-            for (int x = (lo < 0 ? 0 : lo); x < (hi < dim_x ? hi : dim_x); ++x)
-                if (y >= 0 && y < gdim_y) ++cover[(size_t)y * dim_x + x];
+        for (int half = 0; half <= r.twin; ++half)
+            for (int y = r.r0 + half * r.delta; y < r.r1 + half * r.delta; ++y)
+                for (int x = (lo < 0 ? 0 : lo); x < (hi < dim_x ? hi : dim_x); ++x)
+                    if (y >= 0 && y < gdim_y) ++cover[(size_t)y * dim_x + x];
     }
     return t.n_tiles;
 }
