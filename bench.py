@@ -353,47 +353,14 @@ def run_rank(args):
     elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
 
-    # ---- parity of the timed configuration: the p the last timed solve left behind -------------
+    # ---- parity of the timed configuration: the p the last timed solve left behind is downloaded
+    # NOW (with the right-hand side it was solved for); the reference CPU loop runs after all GPU
+    # timing is done -- it keeps the host busy for seconds, during which the GPU clocks fall back
     parity, cpu_rec = None, None
     want_parity = not args.no_cpu_baseline and not (world > 1 and args.no_parity)
     if want_parity:
         got = s.download(capi.FIELD_PRESSURE)
         d_own = s.download(capi.FIELD_DIVERGENCE)
-        if world == 1:
-            want, cpu_rec = cpu_reference_solve(d_own, iters)
-            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
-        else:
-            # the ranks assemble the right-hand side in shared memory, rank 0 runs the reference on
-            # the whole domain (the only way to get exact expectations), every rank checks its slab
-            shm = f"/dev/shm/sfl_bench_{os.environ.get('SFL_RDZV_KEY', str(os.getppid()))}"
-            if rank == 0:
-                d_all = np.lib.format.open_memmap(shm + "_d.npy", mode="w+", dtype=np.float32,
-                                                  shape=(dim_y, size))
-            rdzv.barrier()
-            if rank != 0:
-                d_all = np.load(shm + "_d.npy", mmap_mode="r+")
-            d_all[s.row_begin:s.row_end] = d_own
-            d_all.flush()
-            rdzv.barrier()
-            if rank == 0:
-                want_all, _ = cpu_reference_solve(np.ascontiguousarray(d_all), iters, min_seconds=0.0)
-                np.save(shm + "_p.npy", want_all)
-                del want_all
-            rdzv.barrier()
-            want = np.ascontiguousarray(np.load(shm + "_p.npy", mmap_mode="r")[s.row_begin:s.row_end])
-            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
-            del d_all
-            bad = int(sum(rdzv.all_gather(bad)))
-            if rank == 0:
-                for suffix in ("_d.npy", "_p.npy"):
-                    try:
-                        os.unlink(shm + suffix)
-                    except OSError:
-                        pass
-        parity = {"config": f"poisson_solve {size}x{dim_y} fp32, {iters} iters, omega 1.96, dx 1, the timed "
-                            f"solve's own output vs the reference CPU loop on the same rhs (poisson.cpp:114-125)",
-                  "bit_exact": bad == 0, "cells": cells, "mismatching_cells": bad,
-                  "tolerance": "1e-5 relative allowed by north_star; asserted 0 ulp"}
 
     # ---- full sim step, timed separately (not part of `value`) ---------------------------------
     # A slab reports a back-trace that left its advection halo at synchronize(); every rank still
@@ -429,6 +396,44 @@ def run_rank(args):
     op_us = None
     if world == 1 and args.sim_steps > 0:
         op_us = gpu_operator_times(s, iters, cells)
+
+    # ---- parity: the reference CPU loop on the downloaded right-hand side ----------------------
+    if want_parity:
+        if world == 1:
+            want, cpu_rec = cpu_reference_solve(d_own, iters)
+            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+        else:
+            # the ranks assemble the right-hand side in shared memory, rank 0 runs the reference on
+            # the whole domain (the only way to get exact expectations), every rank checks its slab
+            shm = f"/dev/shm/sfl_bench_{os.environ.get('SFL_RDZV_KEY', str(os.getppid()))}"
+            if rank == 0:
+                d_all = np.lib.format.open_memmap(shm + "_d.npy", mode="w+", dtype=np.float32,
+                                                  shape=(dim_y, size))
+            rdzv.barrier()
+            if rank != 0:
+                d_all = np.load(shm + "_d.npy", mmap_mode="r+")
+            d_all[s.row_begin:s.row_end] = d_own
+            d_all.flush()
+            rdzv.barrier()
+            if rank == 0:
+                want_all, _ = cpu_reference_solve(np.ascontiguousarray(d_all), iters, min_seconds=0.0)
+                np.save(shm + "_p.npy", want_all)
+                del want_all
+            rdzv.barrier()
+            want = np.ascontiguousarray(np.load(shm + "_p.npy", mmap_mode="r")[s.row_begin:s.row_end])
+            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+            del d_all
+            bad = int(sum(rdzv.all_gather(bad)))
+            if rank == 0:
+                for suffix in ("_d.npy", "_p.npy"):
+                    try:
+                        os.unlink(shm + suffix)
+                    except OSError:
+                        pass
+        parity = {"config": f"poisson_solve {size}x{dim_y} fp32, {iters} iters, omega 1.96, dx 1, the timed "
+                            f"solve's own output vs the reference CPU loop on the same rhs (poisson.cpp:114-125)",
+                  "bit_exact": bad == 0, "cells": cells, "mismatching_cells": bad,
+                  "tolerance": "1e-5 relative allowed by north_star; asserted 0 ulp"}
 
     rc = 0
     if rank == 0:

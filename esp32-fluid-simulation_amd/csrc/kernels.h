@@ -79,8 +79,10 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 // the two ranges; dim_x even, 8-byte aligned arrays that lie within 4 GiB of each other, nsweeps
 // >= 4) or 0 (auto = twin).  A flavour whose conditions are not met silently falls back to 2;
 // *lane_cells_used (may be null) receives the flavour that ran.
-#define SFL_MAX_FUSE 16
+#define SFL_MAX_FUSE 24        // depths 18 .. 24: even widths only
+#define SFL_MAX_FUSE_SCALAR 16
 #define SFL_LANE_CELLS_TWIN 22
+bool sor_fused_twin_ok(const float *p_out, const float *p_in, const float *d, const Slab &g);
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells,

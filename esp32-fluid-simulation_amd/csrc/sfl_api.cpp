@@ -298,7 +298,7 @@ sfl::SorParams sor_params(float dx, float omega)
 // 0.19 / 0.21 / 0.23.  Big slabs are VALU / HBM bound and want the deepest fusion; small ones are
 // dominated by the 2 * NS warm-up rows each tile re-streams.  Every rank of a group sees the same
 // thinnest slab, so all ranks resolve the same value.
-int effective_fuse(const sfl_context *c)
+int effective_fuse(const sfl_context *c, float dx = 1.0f)
 {
     int f = c->opt_sor_fuse;
     if (f == 0) {
@@ -307,6 +307,9 @@ int effective_fuse(const sfl_context *c)
     }
     if (f < 2) f = 2;
     if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
+    // depths beyond 16 exist for the twin tiles at dx == 1 only (kernels.h)
+    const bool twin = c->opt_sor_lane_cells != 4 && c->dim_x % 2 == 0 && dx == 1.0f;
+    if (f > SFL_MAX_FUSE_SCALAR && !twin) f = SFL_MAX_FUSE_SCALAR;
     return f & ~1;
 }
 
@@ -338,9 +341,11 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
         ++c->last_launches;
         return SFL_OK;
     }
+    int used = 0;
     HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
                                   c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
-                                  c->opt_sor_rows, c->opt_sor_lane_cells, &c->last_lane_cells));
+                                  c->opt_sor_rows, c->opt_sor_lane_cells, &used));
+    if (used > c->last_lane_cells) c->last_lane_cells = used;  // twin (22) > packed (4) > scalar (2)
     std::swap(c->p, c->p_alt);
     ++c->last_launches;
     return SFL_OK;
@@ -350,7 +355,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
 {
     if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
     std::vector<sfl_context *> peers = peers_of(ctx);
-    const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
+    const int fuse = effective_fuse(ctx, dx), kernel = effective_kernel(ctx);
     std::vector<std::vector<sfl_plan_step>> progs;
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));

@@ -66,6 +66,8 @@ struct WaveCommon {
     }
     template <class P>
     __device__ __forceinline__ void poison(P &) const {}
+    // scheduling fence: nothing is moved across it (pins the order of relax_interleaved)
+    __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ int row_bytes(int r) const { return (r - grow0) * dim_x * 4; }
     __device__ __forceinline__ int load_row_bytes(int r) const
     {
@@ -80,7 +82,7 @@ struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
     static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false;
+    static constexpr bool kRingInRegs = false, kInterleave = false;
     // LDS per wave: the rhs ring (RING rows x 2 planes x 64 lanes x 4 B)
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
@@ -195,7 +197,7 @@ struct Lane4 : WaveCommon {
     using V = v2f;
     using M = Mask2;
     static constexpr int kTileCols = 256, kColAlign = 4, kCells = 4, kPrefetch = 3, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false;
+    static constexpr bool kRingInRegs = false, kInterleave = false;
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 128;
 
     v2f *ring;        // this lane's pair of ring slot 0 / plane 0 in LDS
@@ -301,6 +303,11 @@ struct Twin2 : WaveCommon {
     static constexpr int kPrefetch = SFL_TWIN_PREFETCH;
     static constexpr int kRingAlign = (kPrefetch % 2 == 0) ? kPrefetch : 2 * kPrefetch;
     static constexpr bool kRingInRegs = true;
+#ifdef SFL_TWIN_NO_INTERLEAVE
+    static constexpr bool kInterleave = false;
+#else
+    static constexpr bool kInterleave = true;   // software-pipelined relaxations (sor_stream_core.h)
+#endif
     static constexpr int kRingFloats = 0;
 
     int delta;     // tile B's rows = tile A's rows + delta
@@ -325,21 +332,25 @@ struct Twin2 : WaveCommon {
     __device__ __forceinline__ M mask_and(M m, bool row) const { return m && row; }
     __device__ __forceinline__ V from_lower_lane(V v) const { return v2f{lane_below(v.x), lane_below(v.y)}; }
     __device__ __forceinline__ V from_upper_lane(V v) const { return v2f{lane_above(v.x), lane_above(v.y)}; }
-    // W + E of both halves: two scalar adds with a DPP operand (VOP3P has no DPP form), so that
-    // the seven operations that follow can be packed
+    // W + E of both halves: two SCALAR adds with a DPP operand (VOP3P has no DPP form), so that
+    // the seven operations that follow can be packed.  Written with the DPP builtin (the compiler
+    // folds move + add into v_add_f32_dpp and inserts the wait states a DPP read of a freshly
+    // written VGPR needs -- hand-written asm is invisible to its hazard recognizer: a first version
+    // with inline asm produced wrong bits in one schedule); the empty asm pins each sum to a scalar
+    // register so that the two adds are not re-vectorised into a packed add behind two DPP moves.
     __device__ __forceinline__ V add_from_lower(V v) const
     {
-        V r;
-        asm("v_add_f32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r.x) : "v"(v.x));
-        asm("v_add_f32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r.y) : "v"(v.y));
-        return r;
+        float x = lane_below(v.x) + v.x, y = lane_below(v.y) + v.y;
+        asm("" : "+v"(x));
+        asm("" : "+v"(y));
+        return v2f{x, y};
     }
     __device__ __forceinline__ V add_from_upper(V v) const
     {
-        V r;
-        asm("v_add_f32_dpp %0, %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r.x) : "v"(v.x));
-        asm("v_add_f32_dpp %0, %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(r.y) : "v"(v.y));
-        return r;
+        float x = v.x + lane_above(v.x), y = v.y + lane_above(v.y);
+        asm("" : "+v"(x));
+        asm("" : "+v"(y));
+        return v2f{x, y};
     }
     __device__ __forceinline__ V detach(V v) const
     {
@@ -382,6 +393,9 @@ struct Twin2 : WaveCommon {
 // takes the boundary path, which is correct for every tile.
 template <class B, int NS, bool DX1, bool ZERO_IN, bool TWIN>
 __global__ void __launch_bounds__(kThreads)
+#ifdef SFL_TWIN_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(SFL_TWIN_WAVES_PER_EU)))
+#endif
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t,
                  SorParams prm)
 {
@@ -532,6 +546,14 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
         const long rounds = (tiles + waves - 1) / waves;          // residency rounds
         const double penalty = per_simd >= 2.8 ? 1.0 : per_simd >= 1.9 ? 1.08 : 1.45;
         double cost = (double)(serial > rounds ? serial : rounds) * (rpc + ns + 2) * penalty;
+        if (twin) {
+            // Twin waves are register-bound (2-3 resident per SIMD) and live long: a launch costs
+            // its residency ROUNDS (measured 8192^2, NS = 16: 3052 tiles on 2048 slots = two rounds
+            // of 119 us for 1.5 rounds of work), and a SIMD needs two resident waves to cover the
+            // wait states between dependent packed operations and the memory latency.
+            const double slots = (double)tiles / rounds / simds;  // resident waves per SIMD, last round included
+            cost = (double)rounds * (rpc + ns + 2) * (slots >= 1.8 ? 1.0 : slots >= 1.3 ? 1.15 : 1.5);
+        }
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best_rows = rpc;
@@ -567,6 +589,29 @@ hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float
     return launch_variant<B, NS, false, ZERO_IN, TWIN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
 }
 
+}  // namespace
+
+// Can the twin tiles run on these arrays?  8-byte accesses (even width, aligned) and ONE buffer
+// resource for p_in, d and p_out: they must lie within 4 GiB of each other (a context allocates
+// them in one block, sfl_api.cpp).
+inline bool sor_fused_twin_ok_impl(const float *p_out, const float *p_in, const float *d, const Slab &g)
+{
+    const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
+                          reinterpret_cast<uintptr_t>(d);
+    if ((g.dim_x % 2) != 0 || (all & 7) != 0) return false;
+    const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
+    uintptr_t lo = reinterpret_cast<uintptr_t>(d), hi = lo;
+    for (const void *q : {(const void *)p_out, (const void *)p_in}) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(q);
+        if (!q) continue;
+        lo = a < lo ? a : lo;
+        hi = a > hi ? a : hi;
+    }
+    return hi - lo + bytes <= 0xFFFFFFFFull;
+}
+
+namespace {
+
 // lane_cells: 0 = auto, 2 = scalar 2-cell tiles, 4 = packed 4-cell tiles, 22 = twin tiles (two row
 // ranges per wave, packed).  Auto picks the twin tiles wherever the arrays allow 8-byte accesses.
 template <int NS, bool ZERO_IN>
@@ -577,17 +622,7 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
                           reinterpret_cast<uintptr_t>(d);
     const bool can4 = (g.dim_x % 4 == 0) && (all & 15) == 0 && g.dim_x >= 4;
     const bool can2v = (g.dim_x % 2 == 0) && (all & 7) == 0;
-    // the twin path addresses p_in, d and p_out through ONE buffer resource: they must lie within
-    // 4 GiB of each other (a context allocates them in one block, sfl_api.cpp)
-    const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
-    uintptr_t lo = reinterpret_cast<uintptr_t>(d), hi = lo;
-    for (const void *q : {(const void *)p_out, (const void *)p_in}) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(q);
-        if (!q) continue;
-        lo = a < lo ? a : lo;
-        hi = a > hi ? a : hi;
-    }
-    const bool one_resource = hi - lo + bytes <= 0xFFFFFFFFull;
+    const bool one_resource = sor_fused_twin_ok_impl(p_out, p_in, d, g);
     if (lane_cells == 0) lane_cells = SFL_LANE_CELLS_TWIN;
     if (lane_cells == 4 && can4) {
         *used = 4;
@@ -601,6 +636,25 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     if (can2v)
         return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
     return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+}
+
+// Depths beyond 16 exist for the twin tiles only (the scalar tiles are VALU bound there): the API
+// resolves such a depth only where launch_sor_fused_twin_ok() holds.
+template <int NS>
+hipError_t launch_ns_twin_only(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
+                               int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells, int *used)
+{
+    if (!sor_fused_twin_ok_impl(p_out, p_in, d, g)) return hipErrorInvalidValue;
+    if (lane_cells == SFL_LANE_CELLS_TWIN) {
+        *used = SFL_LANE_CELLS_TWIN;
+        if (p_in == nullptr)
+            return launch_dx<Lane2<NS, true, true>, NS, true, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_dx<Lane2<NS, true, false>, NS, false, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    }
+    *used = 2;
+    if (p_in == nullptr)
+        return launch_dx<Lane2<NS, true, true>, NS, true, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    return launch_dx<Lane2<NS, true, false>, NS, false, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
 }
 
 template <int NS>
@@ -632,6 +686,14 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
                                       int rows_per_chunk, int lane_cells, int *used);
 SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
 SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
+SFL_DECLARE_NS(18) SFL_DECLARE_NS(20) SFL_DECLARE_NS(22) SFL_DECLARE_NS(24)
+#define SFL_DEFINE_NS_TWIN(N)                                                                     \
+    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
+                                      Slab g, int g_begin, int g_end, SorParams prm,              \
+                                      int rows_per_chunk, int lane_cells, int *used)              \
+    {                                                                                             \
+        return launch_ns_twin_only<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used); \
+    }
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(2) SFL_DEFINE_NS(4) SFL_DEFINE_NS(6)
 #endif
@@ -650,8 +712,25 @@ SFL_DEFINE_NS(14)
 #if SFL_NS_GROUP == 5 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(16)
 #endif
+#if SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS_TWIN(18)
+#endif
+#if SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS_TWIN(20)
+#endif
+#if SFL_NS_GROUP == 8 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS_TWIN(22)
+#endif
+#if SFL_NS_GROUP == 9 || SFL_NS_GROUP == -1
+SFL_DEFINE_NS_TWIN(24)
+#endif
 
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
+bool sor_fused_twin_ok(const float *p_out, const float *p_in, const float *d, const Slab &g)
+{
+    return sor_fused_twin_ok_impl(p_out, p_in, d, g);
+}
+
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells, int *lane_cells_used)
@@ -668,6 +747,7 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
     case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
+        SFL_CASE(18) SFL_CASE(20) SFL_CASE(22) SFL_CASE(24)
     }
 #undef SFL_CASE
     return hipErrorInvalidValue;

@@ -171,6 +171,95 @@ constexpr int prologue_trips(int ns, int ring) { return (2 * ns + ring - 1) / ri
 // compiled, eight SGPR spill moves for its buffer descriptor.)
 constexpr bool steady_rows_are_output(int ns, int ring) { return prologue_trips(ns, ring) * ring >= 2 * ns + 1; }
 
+// The NS relaxations of one iteration for interior tiles, SOFTWARE-PIPELINED (backends with
+// B::kInterleave): a relaxation is a chain of five dependent operations
+//     t = ((W+E)+S) + N;  t = rhs - t;  t = -1/4 * t;  t = omega * t;  res = (1-omega)*own + t
+// whose first input N is the previous relaxation's result, and four operations that depend on
+// nothing recent (W+E of both halves, + S, (1-omega)*own).  Issued relaxation after relaxation, a
+// wave stalls on every link of the chain (packed fp32 needs a wait state before a dependent
+// read, and a wave cannot hide its own latency); here the independent part of relaxation s + 1
+// is issued BETWEEN the links of relaxation s, pinned by scheduling fences.  Same operations on
+// the same operands: same bits.  Relaxation index s = 1 .. NS: odd s = E of version (s+1)/2 on
+// row y - s, even s = O of version s/2 on row y - s.
+template <class B, int NS, bool DX1, int TRIP, bool GUARD_STORE, int U>
+SFL_HD void relax_interleaved(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, int y, int out_begin, int out_end)
+{
+    using V = typename B::V;
+    constexpr int RING = ring_of<B, NS>();
+    const V quarter = bk.splat(-0.25f);
+    V ws = bk.splat(0.0f), cown = ws, rhs = ws;  // prepared part of the relaxation about to finish
+    bool have = false;
+#pragma unroll
+    for (int s = 0; s <= NS; ++s) {
+        // ---- which relaxation finishes now (s), which one is prepared meanwhile (nx) ----
+        const bool fin = s >= 1 && pass_runs(TRIP, RING, U, s);
+        int nx = s + 1;
+        while (nx <= NS && !pass_runs(TRIP, RING, U, nx)) ++nx;
+        const bool prep = nx <= NS && (s == 0 || fin || !have);
+        if (s >= 1 && !fin && have) continue;  // (cannot happen: passes join in order, none leaves)
+
+        // operands of the relaxation being prepared
+        const int nrel = U - nx;
+        const int n0 = wrapn(nrel, RING), nm = wrapn(nrel - 1, RING);
+        const bool n_is_e = (nx & 1) != 0, nev = is_even(nrel);
+        // operands of the relaxation being finished
+        const int rel = U - s;
+        const int i0 = wrapn(rel, RING), ip = wrapn(rel + 1, RING);
+        const bool is_e = (s & 1) != 0, ev = is_even(rel);
+
+        V t = ws, we = ws, ncown = cown, nrhs = rhs;
+        if (fin) {
+            t = ws + (is_e ? pp.O[ip] : pp.E[ip]);  // + N
+            bk.fence();
+        }
+        if (prep) {  // W + E: E cell of an even row / O cell of an odd row take W from the lower lane
+            const V oc = n_is_e ? pp.O[n0] : pp.E[n0];
+            const bool lower = n_is_e ? nev : !nev;
+            we = lower ? bk.add_from_lower(oc) : bk.add_from_upper(oc);
+            bk.fence();
+        }
+        if (fin) {
+            t = rhs - t;
+            bk.fence();
+        }
+        if (prep) {
+            ncown = c.one_minus_omega * (n_is_e ? pp.E[n0] : pp.O[n0]);
+            const V d = ring_get<B, NS>(bk, pp, n0, n_is_e ? 0 : 1);
+            nrhs = DX1 ? d : c.dx * d;
+            bk.fence();
+        }
+        if (fin) {
+            t = quarter * t;
+            bk.fence();
+        }
+        if (prep) {
+            we = we + (n_is_e ? pp.O[nm] : pp.E[nm]);  // + S
+            bk.fence();
+        }
+        if (fin) {
+            t = c.omega * t;
+            bk.fence();
+            const V res = cown + t;
+            const V oc = is_e ? pp.O[i0] : pp.E[i0];
+            if (s < NS) {
+                if (is_e) pp.E[i0] = res; else pp.O[i0] = res;
+            } else if (!GUARD_STORE || (y - s >= out_begin && y - s < out_end)) {  // finished row leaves
+                // s == NS is even: an O relaxation; in an even row the O cell is `b`
+                if (ev)
+                    bk.store_row(y - s, oc, res);
+                else
+                    bk.store_row(y - s, res, oc);
+            }
+        }
+        if (prep) {
+            ws = we;
+            cown = ncown;
+            rhs = nrhs;
+            have = true;
+        }
+    }
+}
+
 // The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
 template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool GUARD_STORE, int U>
@@ -210,6 +299,10 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     //   E[r] = E_m (previous iteration), E[r - 1] = E_m (stage m + 1 comes later).  So every
     //   relaxation reads exactly the versions the reference's in-place sweep reads
     //   (poisson.cpp:14-61), and may overwrite its own input register.
+    if constexpr (!EDGE && B::kInterleave) {
+        relax_interleaved<B, NS, DX1, TRIP, GUARD_STORE, U>(bk, pp, c, y, out_begin, out_end);
+        return;
+    }
 #pragma unroll
     for (int m = 1; m <= NS / 2; ++m) {
         // ---- E_m of row y - (2m - 1) ----

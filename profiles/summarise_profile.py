@@ -14,9 +14,10 @@ root = sys.argv[1]
 
 def short(name):
     import re
-    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+), (?:(true|false), )?(true|false)>, \d+, (true|false), (true|false)>", name)
+    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+), (?:(true|false), )?(true|false)>, \d+, (true|false), (true|false)(?:, (true|false))?>", name)
     if m:
-        return (f"sor_fused_kernel<Lane{m.group(1)}, NS={m.group(2)}, dx1={m.group(5)}, "
+        flavour = "Twin" if m.group(7) == "true" else f"Lane{m.group(1)}"
+        return (f"sor_fused_kernel<{flavour}, NS={m.group(2)}, dx1={m.group(5)}, "
                 f"zero_in={m.group(6)}>")
     for key in ("divergence_stream_kernel", "gradient_stream_kernel", "sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
                 "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):

@@ -52,7 +52,8 @@ struct EmuBackend {
     using V = V64;
     using M = M64;
     static constexpr int kPrefetch = 6, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false;
+    static constexpr bool kRingInRegs = false, kInterleave = false;
+    void fence() const {}
 
     const float *p_in;
     const float *d;
@@ -171,7 +172,8 @@ struct EmuTwin {
     using M = bool;
     static constexpr int kPrefetch = EMU_TWIN_PREFETCH;
     static constexpr int kRingAlign = (kPrefetch % 2 == 0) ? kPrefetch : 2 * kPrefetch;
-    static constexpr bool kRingInRegs = true;
+    static constexpr bool kRingInRegs = true, kInterleave = true;
+    void fence() const {}
 
     EmuBackend a;   // memory access of tile A; tile B shifts the rows
     int delta;
