@@ -49,6 +49,7 @@ SOR_FLOPS_PER_CELL_ITER = 8    # one relaxation of an interior cell: 3 neighbour
                                # scale by -1/4, two omega products and their sum (never fused);
                                # SURVEY 8a13 counts 10: dx*d is exact at dx = 1, 1-omega is hoisted
 VALU_CLOCK_GHZ = 2.4           # MI355X max engine clock (MI355X_MICROARCH.md)
+VALU_CYCLES_PER_INSTR = 2.35   # measured issue interval of a plain fp32 wave64 VALU instruction per SIMD
 # algorithmic bytes per cell of the streaming operators (SURVEY.md 8d / BASELINE.md 3)
 OP_BYTES_PER_CELL = {"advect_velocity": 16, "calculate_divergence": 12, "subtract_gradient": 20,
                      "advect_color": 32}
@@ -447,27 +448,25 @@ def run_rank(args):
         pmc = pmc_record((size, dim_y), info["fuse"], world)
         # VALU roofline: the reference's 8 individually rounded fp32 operations per relaxation
         # (poisson.cpp:63-112; contraction to FMA would change results) against the rate at which the
-        # chip issues such operations: 64 lanes x CUs x clock for plain instructions, twice that for
-        # packed ones (v_pk_add_f32 / v_pk_mul_f32 round each half separately).  The kernel's
-        # interior path is packed where the library says so (`packed_fp32` in the solve info).
-        packed = bool(info.get("packed"))
-        valu_peak = cus * 64 * VALU_CLOCK_GHZ / 1e3 * (2 if packed else 1)
+        # chip issues such operations.  Measured on gfx950 (tools/ubench_pk_chain.hip,
+        # profiles/r02_twin_tiles_experiment.txt): a plain fp32 VALU instruction of a wave64 issues
+        # every ~2.35 cycles per SIMD, a packed one every ~4.6 -- the same operation rate either way.
+        valu_peak = cus * 4 * 64 / VALU_CYCLES_PER_INSTR * VALU_CLOCK_GHZ / 1e3
         valu_achieved = value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
         traffic = pmc["traffic_bytes_per_launch"] if pmc else None
         roofline = {
             "bound": "valu", "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
             "frac": valu_achieved / valu_peak,
-            "peak_definition": f"{cus} CUs x 64 lanes x {VALU_CLOCK_GHZ} GHz x {2 if packed else 1} "
-                               f"({'packed' if packed else 'plain'} fp32 VALU operations, no FMA: the "
-                               "reference rounds every product and sum)",
+            "peak_definition": f"{cus} CUs x 4 SIMDs x 64 lanes / {VALU_CYCLES_PER_INSTR} cycles per wave64 "
+                               f"instruction (measured, tools/ubench_pk_chain.hip) x {VALU_CLOCK_GHZ} GHz; "
+                               "plain fp32 operations, no FMA: the reference rounds every product and sum",
             "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
             "avg_launch_us": avg_launch_s * 1e6,
             "traffic": traffic,
             "traffic_source": pmc["source"] if pmc else None,
             "hbm_traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "issued_over_useful": (pmc["valu_wave_insts_per_launch"] * 64
-                                   / (SOR_FLOPS_PER_CELL_ITER * (cells / world) * iters / launches
-                                      / (2 if packed else 1)))
+                                   / (SOR_FLOPS_PER_CELL_ITER * (cells / world) * iters / launches))
             if pmc and pmc.get("valu_wave_insts_per_launch") else None,
             # SURVEY 8d's figure for an UNFUSED sweep (16 B per cell-iteration); a temporally blocked
             # kernel moves a fraction of it, so this is a ratio, not a fraction of a roofline

@@ -72,21 +72,13 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 // p is then implicitly zero, the fused zero-fill of poisson.cpp:117-119) and d, writes the
 // result for global rows [g_begin, g_end) to p_out (p_out must not alias p_in).  Needs p_in
 // valid on rows [g_begin - nsweeps, g_end + nsweeps) and d on one row less each side, clipped
-// to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto; twin tiles: rows
-// of each half).  lane_cells = tile flavour: 2 (scalar fp32, 2 cells per lane, any dim_x), 4
-// (4 cells per lane, packed fp32 over columns; dim_x % 4 == 0 and 16-byte aligned arrays),
-// SFL_LANE_CELLS_TWIN (twin tiles: 2 cells per lane x TWO row ranges per wave, packed fp32 over
-// the two ranges; dim_x even, 8-byte aligned arrays that lie within 4 GiB of each other, nsweeps
-// >= 4) or 0 (auto = twin).  A flavour whose conditions are not met silently falls back to 2;
-// *lane_cells_used (may be null) receives the flavour that ran.
-#define SFL_MAX_FUSE 24        // depths 18 .. 24: even widths only
-#define SFL_MAX_FUSE_SCALAR 16
-#define SFL_LANE_CELLS_TWIN 22
-bool sor_fused_twin_ok(const float *p_out, const float *p_in, const float *d, const Slab &g);
+// to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).  lane_cells =
+// cells per lane: 2 (scalar fp32, any dim_x), 4 (packed fp32, dim_x % 4 == 0 and 16-byte aligned
+// arrays; silently falls back to 2 otherwise) or 0 (auto).
+#define SFL_MAX_FUSE 16
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int lane_cells,
-                            int *lane_cells_used = nullptr);
+                            SorParams prm, int rows_per_chunk, int lane_cells);
 
 // Fill rows [g_begin, g_end) of a float field with zero (poisson.cpp:117-119).
 hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_end);

@@ -89,8 +89,7 @@ struct sfl_context {
     // fields: local arrays of geom.lrows rows (allocated on first use)
     float *vel = nullptr, *vel_tmp = nullptr;
     uint32_t *col = nullptr, *col_tmp = nullptr;
-    // div, p and p_alt are three thirds of ONE allocation (sor_block): the twin-tile SOR kernel
-    // addresses all three through a single buffer resource (they must lie within 4 GiB)
+    // div, p and p_alt are three thirds of ONE allocation (sor_block)
     float *sor_block = nullptr;
     float *div = nullptr;
     float *p = nullptr, *p_alt = nullptr;  // p = current pressure, p_alt = ping-pong partner
@@ -128,7 +127,7 @@ struct sfl_context {
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
 
-    int last_launches = 0, last_exchanges = 0, last_fuse = 0, last_lane_cells = 0;
+    int last_launches = 0, last_exchanges = 0, last_fuse = 0;
 
     size_t local_cells() const { return (size_t)geom.lrows * dim_x; }
     size_t owned_offset_cells() const { return (size_t)ghost * dim_x; }
@@ -298,7 +297,7 @@ sfl::SorParams sor_params(float dx, float omega)
 // 0.19 / 0.21 / 0.23.  Big slabs are VALU / HBM bound and want the deepest fusion; small ones are
 // dominated by the 2 * NS warm-up rows each tile re-streams.  Every rank of a group sees the same
 // thinnest slab, so all ranks resolve the same value.
-int effective_fuse(const sfl_context *c, float dx = 1.0f)
+int effective_fuse(const sfl_context *c)
 {
     int f = c->opt_sor_fuse;
     if (f == 0) {
@@ -307,9 +306,6 @@ int effective_fuse(const sfl_context *c, float dx = 1.0f)
     }
     if (f < 2) f = 2;
     if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
-    // depths beyond 16 exist for the twin tiles at dx == 1 only (kernels.h)
-    const bool twin = c->opt_sor_lane_cells != 4 && c->dim_x % 2 == 0 && dx == 1.0f;
-    if (f > SFL_MAX_FUSE_SCALAR && !twin) f = SFL_MAX_FUSE_SCALAR;
     return f & ~1;
 }
 
@@ -341,11 +337,9 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
         ++c->last_launches;
         return SFL_OK;
     }
-    int used = 0;
     HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
                                   c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
-                                  c->opt_sor_rows, c->opt_sor_lane_cells, &used));
-    if (used > c->last_lane_cells) c->last_lane_cells = used;  // twin (22) > packed (4) > scalar (2)
+                                  c->opt_sor_rows, c->opt_sor_lane_cells));
     std::swap(c->p, c->p_alt);
     ++c->last_launches;
     return SFL_OK;
@@ -355,7 +349,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
 {
     if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
     std::vector<sfl_context *> peers = peers_of(ctx);
-    const int fuse = effective_fuse(ctx, dx), kernel = effective_kernel(ctx);
+    const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
     std::vector<std::vector<sfl_plan_step>> progs;
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
@@ -364,7 +358,6 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
                                           effective_halo(ctx, fuse)));
         c->last_launches = c->last_exchanges = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
-        c->last_lane_cells = 0;
     }
     const sfl::SorParams prm = sor_params(dx, omega);
     if (iters == 0) {  // the reference still zero-fills p (poisson.cpp:117-119)
@@ -661,8 +654,6 @@ static int set_option_one(sfl_context *c, int option, int value)
             return SFL_OK;
         case SFL_OPT_TRANSPORT:
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
-        case SFL_OPT_SOR_LANE_CELLS_USED:
-            return fail(SFL_ERR_INVALID, "SFL_OPT_SOR_LANE_CELLS_USED is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
@@ -672,8 +663,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_sor_halo = value;
             return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS:
-            if (value != 0 && value != 2 && value != 4 && value != SFL_LANE_CELLS_TWIN)
-                return fail(SFL_ERR_INVALID, "tile flavour must be 0 (auto), 2, 4 or %d (twin)", SFL_LANE_CELLS_TWIN);
+            if (value != 0 && value != 2 && value != 4)
+                return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto), 2 or 4");
             c->opt_sor_lane_cells = value;
             return SFL_OK;
     }
@@ -702,7 +693,6 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
-        case SFL_OPT_SOR_LANE_CELLS_USED: *value = c->last_lane_cells; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }

@@ -21,13 +21,6 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = 64 * kWavesPerBlock;
 
-#ifndef SFL_TWIN_PREFETCH
-#define SFL_TWIN_PREFETCH 3   // rows in flight ahead of a twin tile's pipeline
-#endif
-#ifndef SFL_TWIN_MIN_NS
-#define SFL_TWIN_MIN_NS 4     // shallower launches keep the scalar tiles
-#endif
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -66,8 +59,6 @@ struct WaveCommon {
     }
     template <class P>
     __device__ __forceinline__ void poison(P &) const {}
-    // scheduling fence: nothing is moved across it (pins the order of relax_interleaved)
-    __device__ __forceinline__ void fence() const { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ int row_bytes(int r) const { return (r - grow0) * dim_x * 4; }
     __device__ __forceinline__ int load_row_bytes(int r) const
     {
@@ -81,8 +72,7 @@ template <int NS, bool VEC, bool ZERO_IN>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
-    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false, kInterleave = false;
+    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6;
     // LDS per wave: the rhs ring (RING rows x 2 planes x 64 lanes x 4 B)
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
@@ -132,10 +122,6 @@ struct Lane2 : WaveCommon {
         asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));
         return r;
     }
-    // W + E of a cell whose W (E) neighbour sits in the lower (upper) lane: one v_add_f32_dpp
-    __device__ __forceinline__ V add_from_lower(V x) const { return lane_below(x) + x; }
-    __device__ __forceinline__ V add_from_upper(V x) const { return x + lane_above(x); }
-
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
         const int soff = load_row_bytes(r);
@@ -196,8 +182,7 @@ template <int NS, bool ZERO_IN>
 struct Lane4 : WaveCommon {
     using V = v2f;
     using M = Mask2;
-    static constexpr int kTileCols = 256, kColAlign = 4, kCells = 4, kPrefetch = 3, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false, kInterleave = false;
+    static constexpr int kTileCols = 256, kColAlign = 4, kCells = 4, kPrefetch = 3;
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 128;
 
     v2f *ring;        // this lane's pair of ring slot 0 / plane 0 in LDS
@@ -244,8 +229,6 @@ struct Lane4 : WaveCommon {
     // colour vector shifted by one position: {previous lane's .y, own .x} / {own .y, next lane's .x}
     __device__ __forceinline__ V from_lower_lane(V v) const { return v2f{lane_below(v.y), v.x}; }
     __device__ __forceinline__ V from_upper_lane(V v) const { return v2f{v.y, lane_above(v.x)}; }
-    __device__ __forceinline__ V add_from_lower(V v) const { return from_lower_lane(v) + v; }
-    __device__ __forceinline__ V add_from_upper(V v) const { return v + from_upper_lane(v); }
     __device__ __forceinline__ V detach(V v) const
     {
         V r;
@@ -286,116 +269,8 @@ struct Lane4 : WaveCommon {
     }
 };
 
-// ---- twin tiles: 2 cells per lane, TWO row ranges of one strip per wave, packed fp32 ----------
-// V = {value in tile A, value in tile B}: tile A streams rows [r0, r1), tile B rows [r0 + delta,
-// r1 + delta) of the same 128 columns, in lock step.  The two tiles are independent problems of
-// the same shape, so the pipeline of sor_stream_core.h runs unchanged on pairs and every relaxation
-// costs 2 v_add_f32_dpp (W + E of each half) + 7 packed operations for TWO cells instead of 8.5
-// instructions per cell.  Each half is rounded exactly as the scalar instructions round it.
-// Interior tiles only (no masks, -1/4 everywhere).  The right-hand side ring lives in REGISTERS
-// (4 VGPRs per row in flight): no LDS at all on this path, occupancy is set by the VGPR budget
-// (2 waves per SIMD), and the ring costs no DS instruction and no DS latency.
-template <int NS, bool ZERO_IN>
-struct Twin2 : WaveCommon {
-    using V = v2f;
-    using M = bool;
-    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2;
-    static constexpr int kPrefetch = SFL_TWIN_PREFETCH;
-    static constexpr int kRingAlign = (kPrefetch % 2 == 0) ? kPrefetch : 2 * kPrefetch;
-    static constexpr bool kRingInRegs = true;
-#ifdef SFL_TWIN_NO_INTERLEAVE
-    static constexpr bool kInterleave = false;
-#else
-    static constexpr bool kInterleave = true;   // software-pipelined relaxations (sor_stream_core.h)
-#endif
-    static constexpr int kRingFloats = 0;
-
-    int delta;     // tile B's rows = tile A's rows + delta
-    int base_d, base_p, base_o;  // byte offsets of d / p_in / p_out from the base of the one resource (rs_d)
-    int off_a;     // byte offset of the lane's (clamped) cell pair
-    int off_out;   // byte offset of its true column
-    bool a_out;    // the pair lies in the tile's exact interior (dim_x even: pairs never straddle)
-
-    __device__ __forceinline__ void setup(int lane, int x0, int halo, int delta_rows)
-    {
-        delta = delta_rows;
-        const int xa = x0 + 2 * lane;
-        off_a = 4 * min(max(xa, 0), dim_x - 2);
-        off_out = 4 * xa;
-        a_out = xa >= 0 && xa < dim_x && xa >= x0 + halo && xa < x0 + kTileCols - halo;
-    }
-
-    __device__ __forceinline__ V splat(float x) const { return v2f{x, x}; }
-    // the masked operations exist only so that the (never taken) boundary branches of the shared
-    // pipeline source compile
-    __device__ __forceinline__ V select(M m, V a, V b) const { return m ? a : b; }
-    __device__ __forceinline__ M mask_and(M m, bool row) const { return m && row; }
-    __device__ __forceinline__ V from_lower_lane(V v) const { return v2f{lane_below(v.x), lane_below(v.y)}; }
-    __device__ __forceinline__ V from_upper_lane(V v) const { return v2f{lane_above(v.x), lane_above(v.y)}; }
-    // W + E of both halves: two SCALAR adds with a DPP operand (VOP3P has no DPP form), so that
-    // the seven operations that follow can be packed.  Written with the DPP builtin (the compiler
-    // folds move + add into v_add_f32_dpp and inserts the wait states a DPP read of a freshly
-    // written VGPR needs -- hand-written asm is invisible to its hazard recognizer: a first version
-    // with inline asm produced wrong bits in one schedule); the empty asm pins each sum to a scalar
-    // register so that the two adds are not re-vectorised into a packed add behind two DPP moves.
-    __device__ __forceinline__ V add_from_lower(V v) const
-    {
-        float x = lane_below(v.x) + v.x, y = lane_below(v.y) + v.y;
-        asm("" : "+v"(x));
-        asm("" : "+v"(y));
-        return v2f{x, y};
-    }
-    __device__ __forceinline__ V add_from_upper(V v) const
-    {
-        float x = v.x + lane_above(v.x), y = v.y + lane_above(v.y);
-        asm("" : "+v"(x));
-        asm("" : "+v"(y));
-        return v2f{x, y};
-    }
-    __device__ __forceinline__ V detach(V v) const
-    {
-        V r;
-        asm("v_mov_b32 %0, %1" : "=v"(r.x) : "v"(v.x));
-        asm("v_mov_b32 %0, %1" : "=v"(r.y) : "v"(v.y));
-        return r;
-    }
-
-    __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
-    {
-        const int sa = load_row_bytes(r), sb = load_row_bytes(r + delta);
-        const v2f fa = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, sa + base_d, 0));
-        const v2f fb = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, sb + base_d, 0));
-        da = v2f{fa.x, fb.x};
-        db = v2f{fa.y, fb.y};
-        if (!ZERO_IN) {
-            const v2f qa = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, sa + base_p, 0));
-            const v2f qb = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, sb + base_p, 0));
-            pa = v2f{qa.x, qb.x};
-            pb = v2f{qa.y, qb.y};
-        }
-    }
-
-    __device__ __forceinline__ void store_row(int r, V a, V b) const
-    {
-        if (a_out) {
-            const v2f oa = {a.x, b.x}, ob = {a.y, b.y};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, oa), rs_d, off_out, row_bytes(r) + base_o, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, ob), rs_d, off_out, row_bytes(r + delta) + base_o, 0);
-        }
-    }
-    // never called: kRingInRegs
-    __device__ __forceinline__ void ring_store(int, int, V) const {}
-    __device__ __forceinline__ V ring_load(int, int) const { return V{}; }
-};
-
-// TWIN: the kernel's interior path is the twin backend (B must be the 8-byte-access Lane2); the
-// rare interior tile that is not part of a twin tile (grids too small for the twin tiling) then
-// takes the boundary path, which is correct for every tile.
-template <class B, int NS, bool DX1, bool ZERO_IN, bool TWIN>
+template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads)
-#ifdef SFL_TWIN_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(SFL_TWIN_WAVES_PER_EU)))
-#endif
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t,
                  SorParams prm)
 {
@@ -427,7 +302,8 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // front of the branch, its SGPRs live through the register-hungry boundary path too and the
     // allocator parks the store's descriptor in spill lanes, reloading it for every row of the
     // interior path as well (8 v_readlane / v_writelane per row, 6 % of its VALU-class instructions).
-    auto common = [&](WaveCommon &bk) {
+    auto backend = [&]() {
+        B bk;
         bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
         bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
         bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
@@ -436,43 +312,17 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.grow0 = g.grow0;
         bk.row_lo = max(g.grow0, 0);
         bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
-    };
-    if constexpr (TWIN) {
-        if (rect.twin) {  // wave-uniform
-            using T = Twin2<NS, ZERO_IN>;
-            T bk;
-            // ONE buffer resource for the three arrays (the launcher checked that they lie within
-            // 4 GiB of each other): their byte distances ride in the scalar offset of each access
-            const float *lo = d < p_out ? d : p_out;
-            if (!ZERO_IN && p_in < lo) lo = p_in;
-            bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lo), 0, 0xFFFFFFFFu, 0x00020000);
-            bk.base_d = (int)(unsigned)((const char *)d - (const char *)lo);
-            bk.base_p = ZERO_IN ? 0 : (int)(unsigned)((const char *)p_in - (const char *)lo);
-            bk.base_o = (int)(unsigned)((const char *)p_out - (const char *)lo);
-            bk.dim_x = g.dim_x;
-            bk.gdim_y = g.gdim_y;
-            bk.grow0 = g.grow0;
-            bk.row_lo = max(g.grow0, 0);
-            bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
-            bk.setup(lane, x0, t.halo_cols, rect.delta);
-            sor::Consts<T> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
-            const sor::EdgeCell<T> none{};
-            sor::stream_tile<T, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
-            return;
-        }
-    }
-    if (TWIN || sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
-        B bk;
-        common(bk);
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
+        return bk;
+    };
+    if (sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
+        B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
     } else {
-        B bk;
-        common(bk);
-        bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
+        B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
@@ -480,7 +330,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
 }
 
 // Resident waves of one instantiation on the whole device (occupancy query, cached).
-template <class B, int NS, bool DX1, bool ZERO_IN, bool TWIN>
+template <class B, int NS, bool DX1, bool ZERO_IN>
 int resident_waves()
 {
     static int cached = 0;
@@ -488,7 +338,7 @@ int resident_waves()
     int dev = 0, cus = 0, blocks = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, sor_fused_kernel<B, NS, DX1, ZERO_IN, TWIN>,
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, sor_fused_kernel<B, NS, DX1, ZERO_IN>,
                                                      kThreads, 0) != hipSuccess ||
         blocks < 1 || cus < 1) {
         (void)hipGetLastError();
@@ -512,25 +362,15 @@ inline int device_simds()
     return cached;
 }
 
-template <int NS, bool TWIN>
-constexpr int kernel_ring()
-{
-    return TWIN ? (sor::ring_rows(NS, Twin2<NS, false>::kRingAlign) > sor::ring_rows(NS)
-                       ? sor::ring_rows(NS, Twin2<NS, false>::kRingAlign)
-                       : sor::ring_rows(NS))
-                : sor::ring_rows(NS);
-}
-
 // Output rows per interior wave tile (boundary tiles get fewer: sor::make_tiling).  Every tile
 // costs about the same (rpc + 2 NS rows streamed, of which the prologue trips skip ~NS rows' worth
 // of passes), a SIMD works through its tiles essentially one VALU stream at a time, so a launch
 // takes about ceil(tiles / SIMDs) * (rpc + NS) row-steps -- provided each SIMD holds ~2+ waves to cover DS / memory latency (measured on
 // 8192 x {1024, 8192}, profiles/r01_rows_per_chunk.txt: fewer than ~2 waves per SIMD costs 1.4x,
 // 2..3 waves ~1.08x).  Pick the chunk count that minimises that, never exceeding the
-// resident-wave capacity by less than a full round.  Twin tiling: rpc = rows of each half of a
-// twin tile, which costs about one scalar interior tile of rpc rows.
+// resident-wave capacity by less than a full round.
 template <class B>
-int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves, int simds, int twin, int ring)
+int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves, int simds)
 {
     const int rows = g_end - g_begin;
     int best_rows = rows;
@@ -539,21 +379,13 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
         const sor::Tiling t = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                               g_end, rpc, sor::kEdgeRowCost16, twin, ring);
+                                               g_end, rpc, sor::kEdgeRowCost16);
         const long tiles = t.n_tiles;
         const double per_simd = (double)tiles / simds;
         const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
         const long rounds = (tiles + waves - 1) / waves;          // residency rounds
         const double penalty = per_simd >= 2.8 ? 1.0 : per_simd >= 1.9 ? 1.08 : 1.45;
         double cost = (double)(serial > rounds ? serial : rounds) * (rpc + ns + 2) * penalty;
-        if (twin) {
-            // Twin waves are register-bound (2-3 resident per SIMD) and live long: a launch costs
-            // its residency ROUNDS (measured 8192^2, NS = 16: 3052 tiles on 2048 slots = two rounds
-            // of 119 us for 1.5 rounds of work), and a SIMD needs two resident waves to cover the
-            // wait states between dependent packed operations and the memory latency.
-            const double slots = (double)tiles / rounds / simds;  // resident waves per SIMD, last round included
-            cost = (double)rounds * (rpc + ns + 2) * (slots >= 1.8 ? 1.0 : slots >= 1.3 ? 1.15 : 1.5);
-        }
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
             best_rows = rpc;
@@ -563,107 +395,55 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
     return best_rows;
 }
 
-template <class B, int NS, bool DX1, bool ZERO_IN, bool TWIN>
+template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                           int g_begin, int g_end, SorParams prm, int rows_per_chunk)
 {
-    constexpr int ring = kernel_ring<NS, TWIN>();
     const int rpc = rows_per_chunk > 0
                         ? rows_per_chunk
                         : auto_rows_per_chunk<B>(g, g_begin, g_end, NS,
-                                                 resident_waves<B, NS, DX1, ZERO_IN, TWIN>(), device_simds(),
-                                                 TWIN, ring);
+                                                 resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
     const sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                           g_end, rpc, sor::kEdgeRowCost16, TWIN, ring);
+                                           g_end, rpc, sor::kEdgeRowCost16);
     const int blocks = (t.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    sor_fused_kernel<B, NS, DX1, ZERO_IN, TWIN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
+    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
     return hipGetLastError();
 }
 
-template <class B, int NS, bool ZERO_IN, bool TWIN>
+template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                      int g_begin, int g_end, SorParams prm, int rows_per_chunk)
 {
     if (prm.dx == 1.0f)
-        return launch_variant<B, NS, true, ZERO_IN, TWIN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    return launch_variant<B, NS, false, ZERO_IN, TWIN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
 }
 
-}  // namespace
-
-// Can the twin tiles run on these arrays?  8-byte accesses (even width, aligned) and ONE buffer
-// resource for p_in, d and p_out: they must lie within 4 GiB of each other (a context allocates
-// them in one block, sfl_api.cpp).
-inline bool sor_fused_twin_ok_impl(const float *p_out, const float *p_in, const float *d, const Slab &g)
-{
-    const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
-                          reinterpret_cast<uintptr_t>(d);
-    if ((g.dim_x % 2) != 0 || (all & 7) != 0) return false;
-    const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
-    uintptr_t lo = reinterpret_cast<uintptr_t>(d), hi = lo;
-    for (const void *q : {(const void *)p_out, (const void *)p_in}) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(q);
-        if (!q) continue;
-        lo = a < lo ? a : lo;
-        hi = a > hi ? a : hi;
-    }
-    return hi - lo + bytes <= 0xFFFFFFFFull;
-}
-
-namespace {
-
-// lane_cells: 0 = auto, 2 = scalar 2-cell tiles, 4 = packed 4-cell tiles, 22 = twin tiles (two row
-// ranges per wave, packed).  Auto picks the twin tiles wherever the arrays allow 8-byte accesses.
 template <int NS, bool ZERO_IN>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                       int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells, int *used)
+                       int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
     const bool can4 = (g.dim_x % 4 == 0) && (all & 15) == 0 && g.dim_x >= 4;
     const bool can2v = (g.dim_x % 2 == 0) && (all & 7) == 0;
-    const bool one_resource = sor_fused_twin_ok_impl(p_out, p_in, d, g);
-    if (lane_cells == 0) lane_cells = SFL_LANE_CELLS_TWIN;
-    if (lane_cells == 4 && can4) {
-        *used = 4;
-        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    }
-    *used = 2;
-    if (lane_cells == SFL_LANE_CELLS_TWIN && can2v && one_resource && NS >= SFL_TWIN_MIN_NS) {
-        *used = SFL_LANE_CELLS_TWIN;
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    }
+    // auto: the scalar flavour (4 waves / SIMD at fuse 8..12, 3 at 16) measured equal or faster
+    // than the packed one at every fuse depth on 8192^2 (profiles/r01_*); packed is opt-in
+    if (lane_cells == 0) lane_cells = 2;
+    if (lane_cells == 4 && can4)
+        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
     if (can2v)
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-}
-
-// Depths beyond 16 exist for the twin tiles only (the scalar tiles are VALU bound there): the API
-// resolves such a depth only where launch_sor_fused_twin_ok() holds.
-template <int NS>
-hipError_t launch_ns_twin_only(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                               int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells, int *used)
-{
-    if (!sor_fused_twin_ok_impl(p_out, p_in, d, g)) return hipErrorInvalidValue;
-    if (lane_cells == SFL_LANE_CELLS_TWIN) {
-        *used = SFL_LANE_CELLS_TWIN;
-        if (p_in == nullptr)
-            return launch_dx<Lane2<NS, true, true>, NS, true, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-        return launch_dx<Lane2<NS, true, false>, NS, false, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    }
-    *used = 2;
-    if (p_in == nullptr)
-        return launch_dx<Lane2<NS, true, true>, NS, true, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    return launch_dx<Lane2<NS, true, false>, NS, false, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
 }
 
 template <int NS>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells, int *used)
+                     int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used);
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
 }
 
 }  // namespace
@@ -676,24 +456,16 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 #define SFL_DEFINE_NS(N)                                                                          \
     hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
                                       Slab g, int g_begin, int g_end, SorParams prm,              \
-                                      int rows_per_chunk, int lane_cells, int *used)              \
+                                      int rows_per_chunk, int lane_cells)                         \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used); \
+        return launch_ns<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells); \
     }
 #define SFL_DECLARE_NS(N)                                                                         \
     hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
                                       Slab g, int g_begin, int g_end, SorParams prm,              \
-                                      int rows_per_chunk, int lane_cells, int *used);
+                                      int rows_per_chunk, int lane_cells);
 SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
 SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
-SFL_DECLARE_NS(18) SFL_DECLARE_NS(20) SFL_DECLARE_NS(22) SFL_DECLARE_NS(24)
-#define SFL_DEFINE_NS_TWIN(N)                                                                     \
-    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
-                                      Slab g, int g_begin, int g_end, SorParams prm,              \
-                                      int rows_per_chunk, int lane_cells, int *used)              \
-    {                                                                                             \
-        return launch_ns_twin_only<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used); \
-    }
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(2) SFL_DEFINE_NS(4) SFL_DEFINE_NS(6)
 #endif
@@ -712,42 +484,22 @@ SFL_DEFINE_NS(14)
 #if SFL_NS_GROUP == 5 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(16)
 #endif
-#if SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS_TWIN(18)
-#endif
-#if SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS_TWIN(20)
-#endif
-#if SFL_NS_GROUP == 8 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS_TWIN(22)
-#endif
-#if SFL_NS_GROUP == 9 || SFL_NS_GROUP == -1
-SFL_DEFINE_NS_TWIN(24)
-#endif
 
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
-bool sor_fused_twin_ok(const float *p_out, const float *p_in, const float *d, const Slab &g)
-{
-    return sor_fused_twin_ok_impl(p_out, p_in, d, g);
-}
-
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int lane_cells, int *lane_cells_used)
+                            SorParams prm, int rows_per_chunk, int lane_cells)
 {
-    int dummy = 0;
-    int *used = lane_cells_used ? lane_cells_used : &dummy;
     if (g_end <= g_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
         p_out == p_in || p_out == nullptr || d == nullptr ||
-        (lane_cells != 0 && lane_cells != 2 && lane_cells != 4 && lane_cells != SFL_LANE_CELLS_TWIN))
+        (lane_cells != 0 && lane_cells != 2 && lane_cells != 4))
         return hipErrorInvalidValue;
     if (rows_per_chunk > g_end - g_begin) rows_per_chunk = g_end - g_begin;
 #define SFL_CASE(N) \
-    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells, used);
+    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
-        SFL_CASE(18) SFL_CASE(20) SFL_CASE(22) SFL_CASE(24)
     }
 #undef SFL_CASE
     return hipErrorInvalidValue;

@@ -59,11 +59,8 @@ namespace sor {
 
 constexpr int wrapn(int x, int n) { return ((x % n) + n) % n; }
 constexpr bool is_even(int x) { return ((x % 2) + 2) % 2 == 0; }
-// rows of d alive at once (NS + 1), rounded up to a multiple of `align` (2 for the row parity, times
-// the prefetch depth when that is odd); also the unroll factor.  The scalar backends use 6.
-constexpr int ring_rows(int ns, int align = 6) { return ((ns + 1 + align - 1) / align) * align; }
-template <class B, int NS>
-constexpr int ring_of() { return ring_rows(NS, B::kRingAlign); }
+// rows of d alive at once (NS + 1), rounded up to a multiple of 6; also the unroll factor
+constexpr int ring_rows(int ns) { return ((ns + 1 + 5) / 6) * 6; }
 
 // Per-lane facts used only by tiles that touch the domain boundary.
 template <class B>
@@ -92,55 +89,28 @@ struct Consts {
 template <class B, int NS>
 struct Pipe {
     using V = typename B::V;
-    V E[ring_of<B, NS>()];
-    V O[ring_of<B, NS>()];
+    V E[ring_rows(NS)];
+    V O[ring_rows(NS)];
     V pa[B::kPrefetch], pb[B::kPrefetch];  // prefetched p rows (cell a / cell b)
     V da[B::kPrefetch], db[B::kPrefetch];  // prefetched d rows
-    // the right-hand side ring when the backend keeps it in registers (B::kRingInRegs) instead of
-    // LDS: plane 0 = d of the E cells, plane 1 = d of the O cells, indexed like E / O
-    V D[B::kRingInRegs ? 2 : 1][B::kRingInRegs ? ring_of<B, NS>() : 1];
 };
 
-template <class B, int NS>
-SFL_HD void ring_put(B &bk, Pipe<B, NS> &pp, int slot, int plane, typename B::V x)
-{
-    if constexpr (B::kRingInRegs)
-        pp.D[plane][slot] = x;
-    else
-        bk.ring_store(slot, plane, x);
-}
-template <class B, int NS>
-SFL_HD typename B::V ring_get(const B &bk, const Pipe<B, NS> &pp, int slot, int plane)
-{
-    if constexpr (B::kRingInRegs)
-        return pp.D[plane][slot];
-    else
-        return bk.ring_load(slot, plane);
-}
-
 // One relaxation (poisson.cpp:63-112).
-// `oc` = the other colour's cells of the same row (the W / E neighbours: one of them is the lane's
-// own register, the other the neighbouring lane's); `lower`: W comes from the lower lane, else E
-// from the upper one.  The interior path lets the backend form W + E in one step (scalar backends:
-// an add with a DPP operand; the twin backend: one such add per half, then packed arithmetic).
 template <class B, bool EDGE, bool DX1>
-SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, typename B::V oc,
-                           bool lower, typename B::V s, typename B::V n, typename B::V d,
+SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, typename B::V w,
+                           typename B::V e, typename B::V s, typename B::V n, typename B::V d,
                            const EdgeCell<B> &ec, RowFacts rf)
 {
     using V = typename B::V;
     V sum;
     V k;
     if (EDGE) {
-        const V w = lower ? bk.from_lower_lane(oc) : oc;
-        const V e = lower ? oc : bk.from_upper_lane(oc);
         const V z = rf.full ? ec.z_full : bk.splat(0.0f);
         k = rf.full ? ec.k_full : ec.k_part;
         sum = (((z + w) + e) + s) + n;
     } else {
         k = bk.splat(-0.25f);
-        const V we = lower ? bk.add_from_lower(oc) : bk.add_from_upper(oc);  // W + E
-        sum = (we + s) + n;
+        sum = ((w + e) + s) + n;
     }
     const V rhs = DX1 ? d : c.dx * d;
     const V gs = k * (rhs - sum);
@@ -164,101 +134,12 @@ constexpr bool pass_runs(int trip, int ring, int u, int s)
 // The boundary path gets prologue trips only at the shallower fuse depths: at NS >= 14 they push
 // the kernel past 168 VGPRs (3 -> 2 waves per SIMD).
 constexpr bool edge_prologue(int ns) { return ns <= SFL_EDGE_PROLOGUE_MAX_NS; }
-constexpr int prologue_trips(int ns, int ring) { return (2 * ns + ring - 1) / ring; }
+constexpr int prologue_trips(int ns) { return (2 * ns + ring_rows(ns) - 1) / ring_rows(ns); }
 // After the prologue trips the leaving row y - NS is at or above out_begin (the tile starts at
 // out_begin - NS or one row lower), and a full trip never runs past out_end + NS: steady full
 // trips can store without looking.  (A conditional store costs a branch per row and, as
 // compiled, eight SGPR spill moves for its buffer descriptor.)
-constexpr bool steady_rows_are_output(int ns, int ring) { return prologue_trips(ns, ring) * ring >= 2 * ns + 1; }
-
-// The NS relaxations of one iteration for interior tiles, SOFTWARE-PIPELINED (backends with
-// B::kInterleave): a relaxation is a chain of five dependent operations
-//     t = ((W+E)+S) + N;  t = rhs - t;  t = -1/4 * t;  t = omega * t;  res = (1-omega)*own + t
-// whose first input N is the previous relaxation's result, and four operations that depend on
-// nothing recent (W+E of both halves, + S, (1-omega)*own).  Issued relaxation after relaxation, a
-// wave stalls on every link of the chain (packed fp32 needs a wait state before a dependent
-// read, and a wave cannot hide its own latency); here the independent part of relaxation s + 1
-// is issued BETWEEN the links of relaxation s, pinned by scheduling fences.  Same operations on
-// the same operands: same bits.  Relaxation index s = 1 .. NS: odd s = E of version (s+1)/2 on
-// row y - s, even s = O of version s/2 on row y - s.
-template <class B, int NS, bool DX1, int TRIP, bool GUARD_STORE, int U>
-SFL_HD void relax_interleaved(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, int y, int out_begin, int out_end)
-{
-    using V = typename B::V;
-    constexpr int RING = ring_of<B, NS>();
-    const V quarter = bk.splat(-0.25f);
-    V ws = bk.splat(0.0f), cown = ws, rhs = ws;  // prepared part of the relaxation about to finish
-    bool have = false;
-#pragma unroll
-    for (int s = 0; s <= NS; ++s) {
-        // ---- which relaxation finishes now (s), which one is prepared meanwhile (nx) ----
-        const bool fin = s >= 1 && pass_runs(TRIP, RING, U, s);
-        int nx = s + 1;
-        while (nx <= NS && !pass_runs(TRIP, RING, U, nx)) ++nx;
-        const bool prep = nx <= NS && (s == 0 || fin || !have);
-        if (s >= 1 && !fin && have) continue;  // (cannot happen: passes join in order, none leaves)
-
-        // operands of the relaxation being prepared
-        const int nrel = U - nx;
-        const int n0 = wrapn(nrel, RING), nm = wrapn(nrel - 1, RING);
-        const bool n_is_e = (nx & 1) != 0, nev = is_even(nrel);
-        // operands of the relaxation being finished
-        const int rel = U - s;
-        const int i0 = wrapn(rel, RING), ip = wrapn(rel + 1, RING);
-        const bool is_e = (s & 1) != 0, ev = is_even(rel);
-
-        V t = ws, we = ws, ncown = cown, nrhs = rhs;
-        if (fin) {
-            t = ws + (is_e ? pp.O[ip] : pp.E[ip]);  // + N
-            bk.fence();
-        }
-        if (prep) {  // W + E: E cell of an even row / O cell of an odd row take W from the lower lane
-            const V oc = n_is_e ? pp.O[n0] : pp.E[n0];
-            const bool lower = n_is_e ? nev : !nev;
-            we = lower ? bk.add_from_lower(oc) : bk.add_from_upper(oc);
-            bk.fence();
-        }
-        if (fin) {
-            t = rhs - t;
-            bk.fence();
-        }
-        if (prep) {
-            ncown = c.one_minus_omega * (n_is_e ? pp.E[n0] : pp.O[n0]);
-            const V d = ring_get<B, NS>(bk, pp, n0, n_is_e ? 0 : 1);
-            nrhs = DX1 ? d : c.dx * d;
-            bk.fence();
-        }
-        if (fin) {
-            t = quarter * t;
-            bk.fence();
-        }
-        if (prep) {
-            we = we + (n_is_e ? pp.O[nm] : pp.E[nm]);  // + S
-            bk.fence();
-        }
-        if (fin) {
-            t = c.omega * t;
-            bk.fence();
-            const V res = cown + t;
-            const V oc = is_e ? pp.O[i0] : pp.E[i0];
-            if (s < NS) {
-                if (is_e) pp.E[i0] = res; else pp.O[i0] = res;
-            } else if (!GUARD_STORE || (y - s >= out_begin && y - s < out_end)) {  // finished row leaves
-                // s == NS is even: an O relaxation; in an even row the O cell is `b`
-                if (ev)
-                    bk.store_row(y - s, oc, res);
-                else
-                    bk.store_row(y - s, res, oc);
-            }
-        }
-        if (prep) {
-            ws = we;
-            cown = ncown;
-            rhs = nrhs;
-            have = true;
-        }
-    }
-}
+constexpr bool steady_rows_are_output(int ns) { return prologue_trips(ns) * ring_rows(ns) >= 2 * ns + 1; }
 
 // The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
@@ -267,7 +148,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
                     const EdgeCell<B> &ecb, int y, int out_begin, int out_end)
 {
     using V = typename B::V;
-    constexpr int RING = ring_of<B, NS>();
+    constexpr int RING = ring_rows(NS);
     constexpr int kPrefetch = B::kPrefetch;
     constexpr int Q = U % kPrefetch;
 
@@ -278,8 +159,8 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
         // them and has to drain all loads in flight at the loop back-edge to rotate registers)
         V a = bk.detach(pp.pa[Q]), b = bk.detach(pp.pb[Q]);
         const V fa = pp.da[Q], fb = pp.db[Q];
-        ring_put<B, NS>(bk, pp, U, 0, is_even(U) ? fa : fb);  // plane 0: d of the E cell
-        ring_put<B, NS>(bk, pp, U, 1, is_even(U) ? fb : fa);  // plane 1: d of the O cell
+        bk.ring_store(U, 0, is_even(U) ? fa : fb);  // plane 0: d of the E cell
+        bk.ring_store(U, 1, is_even(U) ? fb : fa);  // plane 1: d of the O cell
         bk.load_row(y + kPrefetch, pp.pa[Q], pp.pb[Q], pp.da[Q], pp.db[Q]);
         if (ZERO_IN) a = b = bk.splat(0.0f);  // poisson.cpp:117-119, fused
         if (EDGE) {  // cells outside the domain hold the additive identity
@@ -299,10 +180,6 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     //   E[r] = E_m (previous iteration), E[r - 1] = E_m (stage m + 1 comes later).  So every
     //   relaxation reads exactly the versions the reference's in-place sweep reads
     //   (poisson.cpp:14-61), and may overwrite its own input register.
-    if constexpr (!EDGE && B::kInterleave) {
-        relax_interleaved<B, NS, DX1, TRIP, GUARD_STORE, U>(bk, pp, c, y, out_begin, out_end);
-        return;
-    }
 #pragma unroll
     for (int m = 1; m <= NS / 2; ++m) {
         // ---- E_m of row y - (2m - 1) ----
@@ -314,10 +191,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const bool ev = is_even(rel);            // E cell is `a` in even rows
             const V own = pp.E[i0];
             const V oc = pp.O[i0];
-            const V d = ring_get<B, NS>(bk, pp, i0, 0);
+            const V w = ev ? bk.from_lower_lane(oc) : oc;
+            const V e = ev ? oc : bk.from_upper_lane(oc);
+            const V d = bk.ring_load(i0, 0);
             const RowFacts rf = bk.row_facts(r);
-            // even row: the E cell is `a`, its W neighbour the lower lane's `b`
-            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, oc, ev, pp.O[im], pp.O[ip], d, ev ? eca : ecb, rf);
+            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[im], pp.O[ip], d, ev ? eca : ecb, rf);
         }
         // ---- O_m of row y - 2m ----
         if (pass_runs(TRIP, RING, U, 2 * m)) {
@@ -328,10 +206,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const bool ev = is_even(rel);            // O cell is `b` in even rows
             const V own = pp.O[i0];
             const V oc = pp.E[i0];
-            const V d = ring_get<B, NS>(bk, pp, i0, 1);
+            const V w = ev ? oc : bk.from_lower_lane(oc);
+            const V e = ev ? bk.from_upper_lane(oc) : oc;
+            const V d = bk.ring_load(i0, 1);
             const RowFacts rf = bk.row_facts(r);
-            // even row: the O cell is `b`, its E neighbour the upper lane's `a`
-            const V res = relax<B, EDGE, DX1>(bk, c, own, oc, !ev, pp.E[im], pp.E[ip], d, ev ? ecb : eca, rf);
+            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[im], pp.E[ip], d, ev ? ecb : eca, rf);
             if (m < NS / 2) {
                 pp.O[i0] = res;
             } else if (!GUARD_STORE || (r >= out_begin && r < out_end)) {  // finished row leaves
@@ -356,7 +235,7 @@ SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeC
 {
     const int y_stop = out_end + NS;
     // steady full trips run only after the prologue trips on the paths that have them
-    constexpr bool guard = PARTIAL || TRIP < kSteadyTrip || !steady_rows_are_output(NS, ring_of<B, NS>()) ||
+    constexpr bool guard = PARTIAL || TRIP < kSteadyTrip || !steady_rows_are_output(NS) ||
                            (EDGE && !edge_prologue(NS));
     (void)(((!PARTIAL || y + Us < y_stop) &&
             (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, guard, Us>(bk, pp, c, eca, ecb, y + Us, out_begin,
@@ -370,9 +249,9 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
                         const EdgeCell<B> &ecb, int out_begin, int out_end)
 {
     static_assert(NS >= 2 && NS % 2 == 0, "fuse an even number of colour passes");
-    constexpr int RING = ring_of<B, NS>();
+    constexpr int RING = ring_rows(NS);
     constexpr int kPrefetch = B::kPrefetch;
-    static_assert(RING % 2 == 0 && RING % kPrefetch == 0 && RING >= NS + 1, "ring geometry");
+    static_assert(RING % 6 == 0 && 6 % kPrefetch == 0 && RING >= NS + 1, "ring geometry");
     Pipe<B, NS> pp;
     bk.poison(pp);  // no-op on the GPU; NaN-fills in the emulator to prove nothing stale leaks
 
@@ -389,12 +268,12 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
     if ((!EDGE || edge_prologue(NS)) && y + RING <= y_stop) {  // prologue trips: passes join one by one
         run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 0, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
         y += RING;
-        if (prologue_trips(NS, RING) >= 2 && y + RING <= y_stop) {
+        if (prologue_trips(NS) >= 2 && y + RING <= y_stop) {
             run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
             y += RING;
         }
     }
-    static_assert(prologue_trips(NS, RING) <= kSteadyTrip, "prologue trips");
+    static_assert(prologue_trips(NS) <= kSteadyTrip, "prologue trips");
     for (; y + RING <= y_stop; y += RING)
         run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, false>(bk, pp, c, eca, ecb, y, out_begin,
                                                                     out_end, us);
@@ -419,10 +298,9 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 // the bottom / top of the domain.  Measured on 8192^2, NS = 16: 261 -> 2xx us per launch.
 struct Tiling {
     int ns;               // passes fused
-    int ring;             // largest ring any path of the kernel unrolls by (boundary clearance)
     int dim_x;
     int g_begin, g_end;   // output rows
-    int rows_per_chunk;   // rows of an interior tile (twin tiling: of each HALF of a twin tile)
+    int rows_per_chunk;   // rows of an interior tile
     int rows_edge;        // rows of a tile in a boundary strip
     int rows_first;       // rows of the first chunk of an inner strip (0: no short first chunk)
     int rows_last;        // rows of the last chunk of an inner strip (0: no short last chunk)
@@ -432,15 +310,11 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
-    int twin;             // the middle rows of the inner strips are covered by TWIN tiles
-    int n_twin;           // twin tiles per inner strip
 };
 
 struct TileRect {
     int strip;
     int r0, r1;  // output rows [r0, r1)
-    int twin;    // twin tile: one wave streams rows [r0, r1) AND rows [r0 + delta, r1 + delta)
-    int delta;
 };
 
 SFL_HD int strip_step(const Tiling &t) { return t.tile_cols - 2 * t.halo_cols; }
@@ -466,18 +340,12 @@ SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 }
 
 // `balance16` = 0: every tile gets rows_per_chunk rows; otherwise pass kEdgeRowCost16.
-// `twin` != 0: the kernel's interior path is the twin backend -- one wave relaxes TWO row ranges of
-// its strip with packed arithmetic (sor_fused.hip) at about the cost of one scalar interior tile
-// per row, so the rows of the inner strips that are clear of the bottom / top boundary are cut
-// into twin tiles of two halves of ~rows_per_chunk rows each; `ring` = the largest unroll factor
-// of the kernel's paths.
 SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin,
-                          int g_end, int rows_per_chunk, int balance16, int twin = 0, int ring = 0)
+                          int g_end, int rows_per_chunk, int balance16)
 {
     Tiling t;
     const int rows = g_end - g_begin;
     t.ns = ns;
-    t.ring = ring > ring_rows(ns) ? ring : ring_rows(ns);
     t.dim_x = dim_x;
     t.g_begin = g_begin;
     t.g_end = g_end;
@@ -485,51 +353,32 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
     t.tile_cols = tile_cols;
     t.halo_cols = (ns + col_align - 1) / col_align * col_align;
     t.n_strips = (dim_x + strip_step(t) - 1) / strip_step(t);
-    t.twin = 0;
-    t.n_twin = 0;
 
     int n_right = 0;  // strips whose columns reach the right wall
     while (n_right < t.n_strips && strip_x0(t, t.n_strips - 1 - n_right) + tile_cols >= dim_x) ++n_right;
     t.n_inner = t.n_strips - 1 - n_right;
     if (t.n_inner < 0) t.n_inner = 0;
 
-    // the first / last chunk of an inner strip must be long enough that the rows after / before
-    // it are clear of the boundary (see tile_touches_boundary)
-    const bool bottom = g_begin - ns - 1 <= 0;
-    const bool top = g_end + ns + t.ring >= gdim_y;
-    const int clear_first = ns + 2 - g_begin, clear_last = ns + t.ring + 1 - (gdim_y - g_end);
-
     t.rows_edge = rows_per_chunk;
     t.rows_first = t.rows_last = 0;
-    int re = balance16 > 0 ? balanced_edge_rows(rows_per_chunk, ns, balance16) : 0;
-    if (re <= 0 || re >= rows_per_chunk) re = 0;
-    if (re) {
-        const int first = bottom ? (re > clear_first ? re : clear_first) : 0;
-        const int last = top ? (re > clear_last ? re : clear_last) : 0;
-        t.rows_edge = re;
-        if (first + last + rows_per_chunk <= rows) {
-            t.rows_first = first;
-            t.rows_last = last;
-        }
-    }
-    if (twin && t.n_inner > 0) {
-        const int e = re ? re : rows_per_chunk;
-        const int first = bottom ? (e > clear_first ? e : clear_first) : 0;
-        const int last = top ? (e > clear_last ? e : clear_last) : 0;
-        if (first + last + 2 <= rows) {
-            t.twin = 1;
-            t.rows_first = first;
-            t.rows_last = last;
+    if (balance16 > 0) {
+        const int re = balanced_edge_rows(rows_per_chunk, ns, balance16);
+        if (re > 0 && re < rows_per_chunk) {
+            t.rows_edge = re;
+            // short first / last chunk of the inner strips, long enough that the next chunk is
+            // clear of the boundary (see tile_touches_boundary)
+            const bool bottom = g_begin - ns - 1 <= 0;
+            const bool top = g_end + ns + ring_rows(ns) >= gdim_y;
+            const int first = bottom ? (re > ns + 2 ? re : ns + 2) : 0;
+            const int last = top ? (re > ns + ring_rows(ns) + 1 ? re : ns + ring_rows(ns) + 1) : 0;
+            if (first + last + rows_per_chunk <= rows) {
+                t.rows_first = first;
+                t.rows_last = last;
+            }
         }
     }
     const int mid = rows - t.rows_first - t.rows_last;
-    if (t.twin) {
-        t.n_twin = (mid + 2 * rows_per_chunk - 1) / (2 * rows_per_chunk);
-        if (t.n_twin > mid / 4) t.n_twin = mid / 4 > 0 ? mid / 4 : 1;  // every span holds at least 4 rows
-        t.n_chunks = (t.rows_first > 0) + t.n_twin + (t.rows_last > 0);
-    } else {
-        t.n_chunks = (t.rows_first > 0) + (mid + rows_per_chunk - 1) / rows_per_chunk + (t.rows_last > 0);
-    }
+    t.n_chunks = (t.rows_first > 0) + (mid + rows_per_chunk - 1) / rows_per_chunk + (t.rows_last > 0);
     t.n_chunks_edge = (rows + t.rows_edge - 1) / t.rows_edge;
     t.n_tiles = t.n_inner * t.n_chunks + (t.n_strips - t.n_inner) * t.n_chunks_edge;
     return t;
@@ -540,8 +389,6 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
 SFL_HD TileRect tile_rect(const Tiling &t, int tile)
 {
     TileRect r;
-    r.twin = 0;
-    r.delta = 0;
     const int inner_tiles = t.n_inner * t.n_chunks;
     if (tile < inner_tiles) {
         const int chunk = tile / t.n_inner;
@@ -553,23 +400,6 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile)
         } else if (t.rows_last > 0 && chunk == t.n_chunks - 1) {
             r.r0 = t.g_end - t.rows_last;
             r.r1 = t.g_end;
-        } else if (t.twin) {
-            // The middle rows are split evenly over the strip's twin tiles (span boundaries at
-            // multiples of 4 rows).  A span of L rows is covered by two halves `delta` rows apart;
-            // delta must be EVEN -- both halves run the same iterations, and an iteration's colour
-            // assignment follows the row parity -- so delta = L/2 rounded down to even and each half
-            // has L - delta rows: the halves overlap by up to 3 rows when L is not a multiple of 4
-            // (only a strip's last span can be), where both store the same bits.
-            const int mid_begin = t.g_begin + t.rows_first;
-            const int mid = t.g_end - t.rows_last - mid_begin;
-            const int i = chunk - has_first;
-            const int b = mid_begin + 4 * (int)((long long)(mid / 4) * i / t.n_twin);
-            const int e = i + 1 == t.n_twin ? mid_begin + mid
-                                            : mid_begin + 4 * (int)((long long)(mid / 4) * (i + 1) / t.n_twin);
-            r.delta = ((e - b) / 2) & ~1;
-            r.r0 = b;
-            r.r1 = e - r.delta;
-            r.twin = 1;
         } else {
             const int mid_end = t.g_end - t.rows_last;
             r.r0 = t.g_begin + t.rows_first + (chunk - has_first) * t.rows_per_chunk;
@@ -586,13 +416,13 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile)
     return r;
 }
 
-// does the tile touch the domain boundary (=> EDGE path)?  Twin tiles never do, by construction.
+// does the tile touch the domain boundary (=> EDGE path)?
 SFL_HD bool tile_touches_boundary(const Tiling &t, const TileRect &r, int gdim_y)
 {
     const int x0 = strip_x0(t, r.strip);
     // rows entering the pipeline: [r0 - ns - 1, r1 + ns + ring); columns [x0, x0 + tile_cols)
     return x0 <= 0 || x0 + t.tile_cols >= t.dim_x || r.r0 - t.ns - 1 <= 0 ||
-           r.r1 + r.delta + t.ns + t.ring >= gdim_y;
+           r.r1 + t.ns + ring_rows(t.ns) >= gdim_y;
 }
 
 }  // namespace sor

@@ -199,9 +199,7 @@ class Solver:
     def last_solve_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         capi.check(self._lib.sfl_last_solve_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        lane = self.get_option(capi.OPT_SOR_LANE_CELLS_USED)
-        return {"launches": a.value, "exchanges": b.value, "fuse": c.value, "lane_cells": lane,
-                "packed": lane in (4, capi.LANE_CELLS_TWIN)}
+        return {"launches": a.value, "exchanges": b.value, "fuse": c.value}
 
 
 def _fp(a):

@@ -64,19 +64,14 @@ extern "C" {
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
                                      1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link)  */
-#define SFL_OPT_SOR_LANE_CELLS 5  /* tile flavour of kernel 2: 0 = auto (twin), 2 = scalar fp32, 2
-                                     cells per lane (any width), 4 = 4 cells per lane, packed fp32
-                                     over columns (dim_x % 4 == 0), 22 = twin tiles: 2 cells per
-                                     lane x two row ranges per wave, packed fp32 over the ranges
-                                     (dim_x even, fuse >= 4); unmet conditions fall back to 2     */
+#define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
+                                     width), 4 = packed fp32 (dim_x % 4 == 0; else falls back)    */
 #define SFL_OPT_SOR_HALO 6        /* rows of p exchanged per superstep on a slab (kernel 2): 0 =
                                      auto (64 on slabs of >= 1024 rows, else 32), else fuse..64;
                                      larger = fewer, larger exchanges, more recomputed ghost rows */
 #define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied
                                      inside the dye-advection kernel (one pass over v), 0 = two
                                      kernels                                                     */
-#define SFL_OPT_SOR_LANE_CELLS_USED 8 /* READ ONLY: tile flavour the last poisson_solve's launches
-                                     ran (2, 4 or 22; 0 before the first solve / baseline kernel) */
 
 typedef struct sfl_context sfl_context;
 

@@ -40,20 +40,10 @@ EMU_BINOP(-)
 EMU_BINOP(*)
 #undef EMU_BINOP
 
-// value type of the twin backend: {tile A, tile B}, both halves 64 lanes wide
-struct V64x2 {
-    V64 x, y;
-};
-inline V64x2 operator+(const V64x2 &a, const V64x2 &b) { return {a.x + b.x, a.y + b.y}; }
-inline V64x2 operator-(const V64x2 &a, const V64x2 &b) { return {a.x - b.x, a.y - b.y}; }
-inline V64x2 operator*(const V64x2 &a, const V64x2 &b) { return {a.x * b.x, a.y * b.y}; }
-
 struct EmuBackend {
     using V = V64;
     using M = M64;
-    static constexpr int kPrefetch = 6, kRingAlign = 6;
-    static constexpr bool kRingInRegs = false, kInterleave = false;
-    void fence() const {}
+    static constexpr int kPrefetch = 6;
 
     const float *p_in;
     const float *d;
@@ -100,8 +90,6 @@ struct EmuBackend {
         for (int i = 0; i < 63; ++i) r.l[i] = x.l[i + 1];
         return r;
     }
-    V add_from_lower(const V &x) const { return from_lower_lane(x) + x; }
-    V add_from_upper(const V &x) const { return x + from_upper_lane(x); }
     sfl::sor::RowFacts row_facts(int r) const
     {
         return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
@@ -165,48 +153,6 @@ struct EmuBackend {
     V detach(const V &x) const { return x; }
 };
 
-// The twin backend of the product (sor_fused.hip: Twin2) in emulation: V = {tile A, tile B}, tile B
-// = the same columns `delta` rows further up, the right-hand side ring in pipeline registers.
-struct EmuTwin {
-    using V = V64x2;
-    using M = bool;
-    static constexpr int kPrefetch = EMU_TWIN_PREFETCH;
-    static constexpr int kRingAlign = (kPrefetch % 2 == 0) ? kPrefetch : 2 * kPrefetch;
-    static constexpr bool kRingInRegs = true, kInterleave = true;
-    void fence() const {}
-
-    EmuBackend a;   // memory access of tile A; tile B shifts the rows
-    int delta;
-
-    V splat(float x) const { return {a.splat(x), a.splat(x)}; }
-    V select(M m, const V &p, const V &q) const { return m ? p : q; }
-    M mask_and(M m, bool row) const { return m && row; }
-    V from_lower_lane(const V &v) const { return {a.from_lower_lane(v.x), a.from_lower_lane(v.y)}; }
-    V from_upper_lane(const V &v) const { return {a.from_upper_lane(v.x), a.from_upper_lane(v.y)}; }
-    V add_from_lower(const V &v) const { return {a.add_from_lower(v.x), a.add_from_lower(v.y)}; }
-    V add_from_upper(const V &v) const { return {a.add_from_upper(v.x), a.add_from_upper(v.y)}; }
-    sfl::sor::RowFacts row_facts(int r) const { return a.row_facts(r); }
-    template <class P>
-    void poison(P &pp) const { a.poison(pp); }
-    V detach(const V &v) const { return v; }
-    void load_row(int r, V &pa, V &pb, V &da, V &db) const
-    {
-        a.load_row(r, pa.x, pb.x, da.x, db.x);
-        a.load_row(r + delta, pa.y, pb.y, da.y, db.y);
-    }
-    void store_row(int r, const V &p, const V &q)
-    {
-        a.store_row(r, p.x, q.x);
-        a.tile_r0 += delta;
-        a.tile_r1 += delta;
-        a.store_row(r + delta, p.y, q.y);
-        a.tile_r0 -= delta;
-        a.tile_r1 -= delta;
-    }
-    void ring_store(int, int, const V &) {}
-    V ring_load(int, int) const { return V{}; }
-};
-
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 {
     sfl::sor::EdgeCell<EmuBackend> ec;
@@ -225,12 +171,11 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge, bool balance, bool twin)
+               bool vec2, bool poison, bool force_edge, bool balance)
 {
     using namespace sfl::sor;
-    constexpr int twin_ring = ring_rows(NS, EmuTwin::kRingAlign);
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance ? kEdgeRowCost16 : 0, twin, twin ? twin_ring : 0);
+                                 balance ? kEdgeRowCost16 : 0);
     int stray = 0;
     {
         for (int tile = 0; tile < t.n_tiles; ++tile) {
@@ -256,23 +201,11 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.tile_r1 = r1;
             bk.stray_stores = &stray;
             Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
-            // a twin kernel sends every tile that is not a twin tile down the boundary path
-            const bool edge = force_edge || twin || tile_touches_boundary(t, rect, gdim_y);
+            const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
             const bool dx1 = dx == 1.0f;
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
 #define EMU_RUN(EDGE, DX1, ZERO) stream_tile<EmuBackend, NS, EDGE, DX1, ZERO>(bk, c, eca, ecb, r0, r1)
-            if (rect.twin) {  // the product's twin backend: rows [r0, r1) and [r0 + delta, r1 + delta)
-                if (tile_touches_boundary(t, rect, gdim_y)) return -1000;  // never, by construction
-                EmuTwin tw{bk, rect.delta};
-                Consts<EmuTwin> ct{tw.splat(dx), tw.splat(omega), tw.splat(1.0f - omega)};
-                const EdgeCell<EmuTwin> none{};
-#define EMU_RUN_TWIN(DX1, ZERO) stream_tile<EmuTwin, NS, false, DX1, ZERO>(tw, ct, none, none, r0, r1)
-                if (dx1) { if (zero_in) EMU_RUN_TWIN(true, true); else EMU_RUN_TWIN(true, false); }
-                else     { if (zero_in) EMU_RUN_TWIN(false, true); else EMU_RUN_TWIN(false, false); }
-#undef EMU_RUN_TWIN
-                continue;
-            }
             if (edge) {
                 if (dx1) { if (zero_in) EMU_RUN(true, true, true); else EMU_RUN(true, true, false); }
                 else     { if (zero_in) EMU_RUN(true, false, true); else EMU_RUN(true, false, false); }
@@ -295,13 +228,13 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
-                 bool vec2, bool poison, bool force_edge, bool balance, bool twin
+                 bool vec2, bool poison, bool force_edge, bool balance
 #define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
 #define EMU_DEFINE(N)                                                                             \
     int emu_run_ns##N(EMU_ARGS)                                                                   \
     {                                                                                             \
         return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                            rows_per_chunk, vec2, poison, force_edge, balance, twin);             \
+                            rows_per_chunk, vec2, poison, force_edge, balance);                   \
     }
 EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
 EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
@@ -320,20 +253,18 @@ EMU_DEFINE(16)
 
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
-//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
-//        bit4 = twin tiling: the middle rows of the inner strips run the twin backend
+//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles)
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
               int lrows, int g_begin, int g_end, int ns, float dx, float omega,
               int rows_per_chunk, int flags)
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
-    const bool twin = flags & 16;
-    if ((vec2 || twin) && (dim_x & 1)) return -1;
+    if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
         return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
-                             omega, rows_per_chunk, vec2 || twin, poison, force_edge, balance, twin) ? -3 : 0;
+                             omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)
@@ -349,25 +280,21 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 // of rows [g_begin, g_end) and 0 elsewhere.
 extern "C" __attribute__((visibility("default"))) int
 emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin, int g_end,
-                 int rows_per_chunk, int balance, int twin, int *cover, int *n_edge)
+                 int rows_per_chunk, int balance, int *cover, int *n_edge)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance, twin, twin ? ring_rows(ns, 6) : 0);
+                                 balance);
     *n_edge = 0;
     for (int tile = 0; tile < t.n_tiles; ++tile) {
         const TileRect r = tile_rect(t, tile);
         if (r.strip < 0 || r.strip >= t.n_strips || r.r0 >= r.r1) return -1;
-        if (tile_touches_boundary(t, r, gdim_y)) {
-            if (r.twin) return -2;  // twin tiles are interior tiles by construction
-            ++*n_edge;
-        }
+        if (tile_touches_boundary(t, r, gdim_y)) ++*n_edge;
         const int x0 = strip_x0(t, r.strip);
         const int lo = x0 + t.halo_cols, hi = x0 + t.tile_cols - t.halo_cols;
-        for (int half = 0; half <= r.twin; ++half)
-            for (int y = r.r0 + half * r.delta; y < r.r1 + half * r.delta; ++y)
-                for (int x = (lo < 0 ? 0 : lo); x < (hi < dim_x ? hi : dim_x); ++x)
-                    if (y >= 0 && y < gdim_y) ++cover[(size_t)y * dim_x + x];
+        for (int y = r.r0; y < r.r1; ++y)
+            for (int x = (lo < 0 ? 0 : lo); x < (hi < dim_x ? hi : dim_x); ++x)
+                if (y >= 0 && y < gdim_y) ++cover[(size_t)y * dim_x + x];
     }
     return t.n_tiles;
 }

@@ -60,11 +60,10 @@ SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (64, 48), (127, 33),
 def test_sor_fused_vs_oracle(sfl, oracle, dim_x, dim_y):
     _, _, d = random_fields(dim_x, dim_y, 3)
     for fuse, iters, rows in [(2, 1, 0), (4, 3, 16), (8, 4, 0), (8, 9, 24), (16, 8, 0), (6, 7, 0)]:
-        for lane in (0, 2):     # auto = twin tiles where the width is even; 2 = scalar tiles
-            hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_rows=rows, sor_lane_cells=lane)
-            assert_bit_equal(hp.poisson_solve(d, 1.0, iters, OMEGA),
-                             oracle.poisson_solve(d, 1.0, iters, OMEGA),
-                             f"{dim_x}x{dim_y} fuse {fuse} iters {iters} lane {lane}")
+        hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_rows=rows)
+        assert_bit_equal(hp.poisson_solve(d, 1.0, iters, OMEGA),
+                         oracle.poisson_solve(d, 1.0, iters, OMEGA),
+                         f"{dim_x}x{dim_y} fuse {fuse} iters {iters}")
     hp = sfl.HostPath(sor_kernel=2, sor_fuse=8)
     assert_bit_equal(hp.poisson_solve(d, 0.5, 5, np.float32(1.3)),
                      oracle.poisson_solve(d, 0.5, 5, np.float32(1.3)), "dx 0.5 omega 1.3")
@@ -234,7 +233,7 @@ def test_headline_size_spot_check_vs_oracle(sfl, oracle):
     rng = np.random.default_rng(2026)
     d = (rng.standard_normal((n, n)) * 0.05).astype(np.float32)
     want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
-    for lane, fuse in ((22, 16), (2, 16), (22, 12), (4, 16)):
+    for lane, fuse in ((2, 16), (2, 12), (4, 16)):
         with sfl.Solver(n, n) as s:
             s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
             s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
@@ -245,7 +244,6 @@ def test_headline_size_spot_check_vs_oracle(sfl, oracle):
             info = s.last_solve_info()
             got = s.download(sfl.capi.FIELD_PRESSURE)
         assert info["fuse"] == fuse and info["launches"] == -(-2 * iters // fuse)
-        assert info["lane_cells"] == lane
         assert_bit_equal(got, want, f"8192^2 lane{lane} fuse{fuse}")
 
 
@@ -265,7 +263,6 @@ def test_baseline_config3_exactly_as_benchmarked(sfl, oracle):
         s.synchronize()
         got = s.download(sfl.capi.FIELD_PRESSURE)
     assert info["fuse"] == 16 and info["launches"] == 10 and info["exchanges"] == 0
-    assert info["lane_cells"] == sfl.capi.LANE_CELLS_TWIN and info["packed"]
     assert_bit_equal(got, oracle.poisson_solve(d, 1.0, iters, OMEGA), "C3: 8192^2 x 80 iterations, auto")
 
 
@@ -296,7 +293,7 @@ def test_large_grid_properties(sfl):
         d = (rng.standard_normal((n, n)) * 0.1).astype(np.float32)
         s.upload(sfl.capi.FIELD_DIVERGENCE, d)
         results = []
-        for kernel, fuse, lane in ((1, 0, 0), (2, 6, 22), (2, 16, 2), (2, 4, 4), (2, 6, 22), (2, 16, 22)):
+        for kernel, fuse, lane in ((1, 0, 0), (2, 6, 2), (2, 16, 2), (2, 4, 4), (2, 6, 2)):
             s.set_option(sfl.capi.OPT_SOR_KERNEL, kernel)
             if fuse:
                 s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
@@ -335,7 +332,7 @@ def test_api_error_paths(sfl):
     with sfl.Solver(32, 16) as s:
         for opt, bad in ((cap.OPT_SOR_KERNEL, 3), (cap.OPT_SOR_FUSE, 7), (cap.OPT_SOR_FUSE, 18),
                          (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_ADVECT_HALO, 0), (cap.OPT_SOR_HALO, 1),
-                         (cap.OPT_SOR_LANE_CELLS_USED, 2), (99, 0)):
+                         (99, 0)):
             with pytest.raises(sfl.SflError) as e:
                 s.set_option(opt, bad)
             assert e.value.code == cap.ERR_INVALID
@@ -386,7 +383,7 @@ def test_randomised_configurations_vs_oracle(sfl, oracle):
         iters = int(rng.integers(1, 14))
         fuse = int(rng.choice([2, 4, 6, 8, 10, 12, 14, 16]))
         rows = int(rng.choice([0, 0, 8, 17, 40]))
-        lane = int(rng.choice([2, 4, 22, 22]))
+        lane = int(rng.choice([2, 4]))
         dx = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
         omega = np.float32(rng.choice([1.96, 1.0, 1.7]))
         nranks = int(rng.choice([1, 1, 2, 3]))
@@ -620,42 +617,3 @@ def test_group_options_are_group_wide(sfl, oracle):
         for s in slabs:
             s.close()
     assert_bit_equal(got, want, "advection with a group-wide 12-row halo")
-
-
-TWIN_SHAPES = [(256, 200), (258, 300), (640, 150), (1000, 97), (386, 64), (2048, 1100), (130, 4000)]
-
-
-@pytest.mark.parametrize("dim_x,dim_y", TWIN_SHAPES)
-def test_sor_twin_tiles_vs_oracle(sfl, oracle, dim_x, dim_y):
-    """Twin tiles (two row ranges of a strip per wave, packed fp32 over the two ranges, rhs ring in
-    registers; boundary tiles on the scalar EDGE path): every fuse depth, forced and automatic rows
-    per tile, from zero and continuing, dx = 1 and dx != 1 -- same bits as the oracle."""
-    _, _, d = random_fields(dim_x, dim_y, 9)
-    for fuse, iters, rows in [(4, 2, 0), (4, 5, 11), (6, 6, 0), (8, 4, 7), (8, 9, 24), (10, 5, 0), (12, 6, 0),
-                              (12, 13, 9), (14, 7, 20), (16, 8, 0), (16, 17, 13)]:
-        with sfl.Solver(dim_x, dim_y) as s:
-            s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
-            s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
-            s.set_option(sfl.capi.OPT_SOR_ROWS, rows)
-            s.set_option(sfl.capi.OPT_SOR_LANE_CELLS, sfl.capi.LANE_CELLS_TWIN)
-            s.upload(sfl.capi.FIELD_DIVERGENCE, d)
-            s.poisson_solve(1.0, iters, OMEGA)
-            s.synchronize()
-            assert s.last_solve_info()["lane_cells"] == sfl.capi.LANE_CELLS_TWIN
-            assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, iters, OMEGA),
-                             f"twin {dim_x}x{dim_y} fuse {fuse} iters {iters} rows {rows}")
-    hp = sfl.HostPath(sor_kernel=2, sor_fuse=12, sor_lane_cells=sfl.capi.LANE_CELLS_TWIN)
-    assert_bit_equal(hp.poisson_solve(d, 0.5, 7, np.float32(1.3)),
-                     oracle.poisson_solve(d, 0.5, 7, np.float32(1.3)), "twin dx 0.5 omega 1.3")
-
-
-def test_twin_falls_back_on_odd_widths(sfl, oracle):
-    """Twin tiles need 8-byte accesses: an odd width silently runs the scalar tiles (and says so)."""
-    _, _, d = random_fields(301, 90, 10)
-    with sfl.Solver(301, 90) as s:
-        s.set_option(sfl.capi.OPT_SOR_LANE_CELLS, sfl.capi.LANE_CELLS_TWIN)
-        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
-        s.poisson_solve(1.0, 8, OMEGA)
-        s.synchronize()
-        assert s.last_solve_info()["lane_cells"] == 2
-        assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, 8, OMEGA), "odd width")

@@ -25,17 +25,17 @@ def emu():
     lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
     lib.emu_sor_fused.restype = C.c_int
 
-    lib.emu_tiling_cover.argtypes = [C.c_int] * 10 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.emu_tiling_cover.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.emu_tiling_cover.restype = C.c_int
 
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
-            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, twin=False):
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False):
         lrows, dim_x = d.shape
         gdim_y = lrows if gdim_y is None else gdim_y
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (16 if twin else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
         assert rc == 0
@@ -104,14 +104,11 @@ def test_slab_launch_matches_whole_domain(emu, oracle, nranks, ns):
 
 
 def test_tilings_partition_the_row_range(emu):
-    """Property of the product's tiling arithmetic (uniform, boundary-balanced and twin; both lane
+    """Property of the product's tiling arithmetic (uniform and boundary-balanced, both lane
     flavours): every cell of the launch's row range is stored by exactly one tile, nothing outside
-    it is touched, and balancing only ever shortens boundary tiles.  Twin tiling: twin tiles never
-    touch the boundary, and the only cells stored twice (with identical bits) are those of the up to
-    three rows the two halves of a strip's last span share when it is not a multiple of 4 rows."""
+    it is touched, and balancing only ever shortens boundary tiles."""
     rng = np.random.default_rng(11)
-    cases = [(16, 8192, 8192, 0, 8192, 234), (8, 8192, 8192, 1024, 2048, 38), (16, 300, 200, 0, 200, 200),
-             (12, 8192, 8192, 1024, 2048, 22), (12, 8192, 8192, 0, 1024, 22), (12, 8192, 8192, 7104, 8192, 30)]
+    cases = [(16, 8192, 8192, 0, 8192, 234), (8, 8192, 8192, 1024, 2048, 38), (16, 300, 200, 0, 200, 200)]
     for _ in range(150):
         ns = int(rng.choice([2, 4, 8, 12, 16]))
         dim_x, gdim_y = int(rng.integers(2, 700)), int(rng.integers(2, 400))
@@ -124,70 +121,13 @@ def test_tilings_partition_the_row_range(emu):
         for tile_cols, align in ((128, 2), (256, 4)):
             counts = {}
             for balance in (0, 10, 7, 13):
-                for twin in ((0, 1) if tile_cols == 128 else (0,)):
-                    cover = np.zeros((gdim_y, dim_x), np.int32)
-                    n_edge = C.c_int(0)
-                    n = emu.lib.emu_tiling_cover(ns, tile_cols, align, dim_x, gdim_y, g_begin, g_end, rpc, balance,
-                                                 twin, cover.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n_edge))
-                    tag = f"ns {ns} {dim_x}x{gdim_y} rows [{g_begin},{g_end}) rpc {rpc} cols {tile_cols} " \
-                          f"balance {balance} twin {twin}"
-                    assert n > 0, tag
-                    assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
-                    if twin:
-                        assert (cover[g_begin:g_end] >= 1).all() and (cover[g_begin:g_end] <= 2).all(), tag
-                        twice = (cover[g_begin:g_end] == 2)
-                        assert (twice.sum(axis=0) <= 3).all(), tag      # <= 3 shared rows per strip
-                    else:
-                        assert (cover[g_begin:g_end] == 1).all(), tag
-                        counts[balance] = n
+                cover = np.zeros((gdim_y, dim_x), np.int32)
+                n_edge = C.c_int(0)
+                n = emu.lib.emu_tiling_cover(ns, tile_cols, align, dim_x, gdim_y, g_begin, g_end, rpc, balance,
+                                             cover.ctypes.data_as(C.POINTER(C.c_int)), C.byref(n_edge))
+                tag = f"ns {ns} {dim_x}x{gdim_y} rows [{g_begin},{g_end}) rpc {rpc} cols {tile_cols} balance {balance}"
+                assert n > 0, tag
+                assert (cover[g_begin:g_end] == 1).all(), tag
+                assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
+                counts[balance] = n
             assert counts[10] >= counts[0]
-
-
-TWIN_CASES = [(420, 260, 40), (258, 300, 64), (640, 150, 24), (1000, 97, 9), (386, 64, 3)]
-
-
-@pytest.mark.parametrize("ns", [4, 8, 12, 16])
-@pytest.mark.parametrize("dim_x,dim_y,rows", TWIN_CASES)
-def test_twin_tiles_on_interior_rows(emu, oracle, ns, dim_x, dim_y, rows):
-    """The twin backend (two row ranges of a strip per wave, {A, B} value pairs, rhs ring in pipeline
-    registers) on the middle rows of the inner strips, boundary tiles on the scalar EDGE path: the
-    same pipeline source, bit-exact against the oracle from zero and from a given p, dx = 1 and
-    dx != 1, NaN-poisoned state, odd and even spans."""
-    rng = np.random.default_rng(ns * 7 + dim_x)
-    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
-    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
-    assert_bit_equal(emu(None, d, ns, rows=rows, twin=True), oracle.poisson_solve(d, 1.0, ns // 2, OMEGA),
-                     "twin, from zero")
-    assert_bit_equal(emu(p0, d, ns, rows=rows, twin=True), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA),
-                     "twin, continue")
-    assert_bit_equal(emu(p0, d, ns, rows=rows, twin=True, dx=0.5, omega=np.float32(1.4)),
-                     oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "twin, dx and omega")
-    assert_bit_equal(emu(p0, d, ns, rows=rows, twin=True, uniform=True),
-                     oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "twin, unbalanced boundary tiles")
-
-
-@pytest.mark.parametrize("nranks", [2, 3])
-@pytest.mark.parametrize("ns", [8, 12])
-def test_twin_tiles_on_a_slab(emu, oracle, nranks, ns):
-    """Twin tiling of a slab launch (local array with ghost rows, output range extended into them):
-    an interior slab has no boundary rows at all, so every inner-strip row is twin-tiled."""
-    dim_x, dim_y, ghost = 300, 180, 24
-    rng = np.random.default_rng(5)
-    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
-    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
-    want = oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA)
-    for r in range(nranks):
-        g0, g1 = dim_y * r // nranks, dim_y * (r + 1) // nranks
-        grow0 = g0 - ghost
-        for extra in (0, 6):     # output rows own +- extra (a launch inside a superstep)
-            o0, o1 = max(g0 - extra, 0), min(g1 + extra, dim_y)
-
-            def local(a, halo):
-                l = np.full((g1 - g0 + 2 * ghost, dim_x), np.nan, np.float32)
-                a0, a1 = max(o0 - halo, 0), min(o1 + halo, dim_y)
-                l[a0 - grow0:a1 - grow0] = a[a0:a1]
-                return l
-            out = np.full((g1 - g0 + 2 * ghost, dim_x), np.nan, np.float32)
-            emu(local(p0, ns), local(d, ns - 1), ns, rows=13, gdim_y=dim_y, grow0=grow0, g_begin=o0,
-                g_end=o1, out=out, twin=True)
-            assert_bit_equal(out[o0 - grow0:o1 - grow0], want[o0:o1], f"slab {r}/{nranks} extra {extra}")
