@@ -49,7 +49,8 @@ SOR_FLOPS_PER_CELL_ITER = 8    # one relaxation of an interior cell: 3 neighbour
                                # scale by -1/4, two omega products and their sum (never fused);
                                # SURVEY 8a13 counts 10: dx*d is exact at dx = 1, 1-omega is hoisted
 VALU_CLOCK_GHZ = 2.4           # MI355X max engine clock (MI355X_MICROARCH.md)
-VALU_CYCLES_PER_INSTR = 2.35   # measured issue interval of a plain fp32 wave64 VALU instruction per SIMD
+VALU_LANES_PER_SIMD_CLK = 32   # a plain fp32 wave64 VALU instruction issues every 2 cycles per SIMD (measured:
+                               # 2.35-2.5 "cycles at 2.4 GHz" at the sustained clock, profiles/r02_ubench_pk_chain.log)
 # algorithmic bytes per cell of the streaming operators (SURVEY.md 8d / BASELINE.md 3)
 OP_BYTES_PER_CELL = {"advect_velocity": 16, "calculate_divergence": 12, "subtract_gradient": 20,
                      "advect_color": 32}
@@ -451,15 +452,16 @@ def run_rank(args):
         # chip issues such operations.  Measured on gfx950 (tools/ubench_pk_chain.hip,
         # profiles/r02_twin_tiles_experiment.txt): a plain fp32 VALU instruction of a wave64 issues
         # every ~2.35 cycles per SIMD, a packed one every ~4.6 -- the same operation rate either way.
-        valu_peak = cus * 4 * 64 / VALU_CYCLES_PER_INSTR * VALU_CLOCK_GHZ / 1e3
+        valu_peak = cus * 4 * VALU_LANES_PER_SIMD_CLK * VALU_CLOCK_GHZ / 1e3
         valu_achieved = value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
         traffic = pmc["traffic_bytes_per_launch"] if pmc else None
         roofline = {
             "bound": "valu", "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
             "frac": valu_achieved / valu_peak,
-            "peak_definition": f"{cus} CUs x 4 SIMDs x 64 lanes / {VALU_CYCLES_PER_INSTR} cycles per wave64 "
-                               f"instruction (measured, tools/ubench_pk_chain.hip) x {VALU_CLOCK_GHZ} GHz; "
-                               "plain fp32 operations, no FMA: the reference rounds every product and sum",
+            "peak_definition": f"{cus} CUs x 4 SIMDs x {VALU_LANES_PER_SIMD_CLK} fp32 lanes per clock x "
+                               f"{VALU_CLOCK_GHZ} GHz = half of the chip's 157.3 TFLOP/s fp32 vector peak "
+                               "(an FMA counts two; the reference rounds every product and sum, so no FMA); a "
+                               "wave64 instruction issues every 2 cycles (profiles/r02_ubench_pk_chain.log)",
             "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
             "avg_launch_us": avg_launch_s * 1e6,
             "traffic": traffic,
