@@ -14,6 +14,7 @@ OPT_SOR_KERNEL, OPT_SOR_FUSE, OPT_ADVECT_HALO, OPT_SOR_ROWS, OPT_TRANSPORT = 0, 
 OPT_SOR_LANE_CELLS = 5
 OPT_SOR_HALO = 6
 OPT_FUSE_PROJECTION = 7
+OPT_SOR_OVERLAP = 8
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 

@@ -70,14 +70,20 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 // Fused streaming kernel: `nsweeps` (even, 2..SFL_MAX_FUSE) consecutive colour passes,
 // starting with `first_colour`, in ONE launch.  Reads p_in (or nothing when p_in == nullptr:
 // p is then implicitly zero, the fused zero-fill of poisson.cpp:117-119) and d, writes the
-// result for global rows [g_begin, g_end) to p_out (p_out must not alias p_in).  Needs p_in
+// result for the global rows of `rows` to p_out (p_out must not alias p_in).  Needs p_in
 // valid on rows [g_begin - nsweeps, g_end + nsweeps) and d on one row less each side, clipped
 // to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).  lane_cells =
 // cells per lane: 2 (scalar fp32, any dim_x), 4 (packed fp32, dim_x % 4 == 0 and 16-byte aligned
 // arrays; silently falls back to 2 otherwise) or 0 (auto).
+// One launch covers output rows [g_begin, g_end) and, optionally, a second disjoint range
+// [g2_begin, g2_end) (the two cut-adjacent bands of a slab around a halo exchange in ONE launch).
 #define SFL_MAX_FUSE 16
+struct SorRows {
+    int g_begin, g_end;
+    int g2_begin, g2_end;
+};
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
-                            Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
+                            Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells);
 
 // Fill rows [g_begin, g_end) of a float field with zero (poisson.cpp:117-119).

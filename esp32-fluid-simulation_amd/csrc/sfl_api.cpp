@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -85,6 +86,10 @@ struct sfl_context {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // halo exchanges of a solve run on their own stream so that they overlap the launches that do
+    // not depend on them (a slab with RCCL transport; a linked group keeps these in Group)
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_arrived = nullptr;
 
     // fields: local arrays of geom.lrows rows (allocated on first use)
     float *vel = nullptr, *vel_tmp = nullptr;
@@ -121,7 +126,7 @@ struct sfl_context {
     float *host_scratch = nullptr;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1;
+        opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -139,7 +144,15 @@ namespace {
 struct Group {
     std::vector<sfl_context *> members;
     hipStream_t stream = nullptr;
-    ~Group() { if (stream) (void)hipStreamDestroy(stream); }
+    hipStream_t xstream = nullptr;  // in-process halo copies of a solve (see sfl_context::xstream)
+    hipEvent_t ev_ready = nullptr, ev_arrived = nullptr;
+    ~Group()
+    {
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_arrived) (void)hipEventDestroy(ev_arrived);
+        if (xstream) (void)hipStreamDestroy(xstream);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 int use_device(sfl_context *c)
@@ -219,7 +232,8 @@ int min_owned_rows(const sfl_context *c)
 // ---- halo exchange ---------------------------------------------------------------------
 // Every rank sends its `rows` lowest owned rows down and its `rows` highest owned rows up, and
 // receives the neighbours' into the ghost rows adjacent to its owned block.
-int exchange(const std::vector<sfl_context *> &peers, int field, int rows)
+// `on` = stream to issue the transfers on (nullptr: the contexts' compute stream).
+int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipStream_t on = nullptr)
 {
     if (rows <= 0) return SFL_OK;
     sfl_context *any = peers[0];
@@ -247,12 +261,12 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows)
             if (c->rank > 0) {
                 sfl_context *lo = peers[c->rank - 1];
                 HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - rows), row_ptr(lo, lo->g1 - rows), bytes,
-                                       hipMemcpyDeviceToDevice, c->stream));
+                                       hipMemcpyDeviceToDevice, on ? on : c->stream));
             }
             if (c->rank < c->nranks - 1) {
                 sfl_context *hi = peers[c->rank + 1];
                 HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1), row_ptr(hi, hi->g0), bytes,
-                                       hipMemcpyDeviceToDevice, c->stream));
+                                       hipMemcpyDeviceToDevice, on ? on : c->stream));
             }
         }
         return SFL_OK;
@@ -263,16 +277,15 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows)
         return fail(SFL_ERR_STATE, "slab %d/%d has no communicator: call sfl_comm_attach() or "
                     "sfl_group_link() first", c->rank, c->nranks);
     SFL_TRY(use_device(c));
+    hipStream_t st = on ? on : c->stream;
     NCCL_TRY(ncclGroupStart());
     if (c->rank > 0) {
-        NCCL_TRY(ncclSend(row_ptr(c, c->g0), bytes, ncclChar, c->rank - 1, c->comm, c->stream));
-        NCCL_TRY(ncclRecv(row_ptr(c, c->g0 - rows), bytes, ncclChar, c->rank - 1, c->comm,
-                          c->stream));
+        NCCL_TRY(ncclSend(row_ptr(c, c->g0), bytes, ncclChar, c->rank - 1, c->comm, st));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g0 - rows), bytes, ncclChar, c->rank - 1, c->comm, st));
     }
     if (c->rank < c->nranks - 1) {
-        NCCL_TRY(ncclSend(row_ptr(c, c->g1 - rows), bytes, ncclChar, c->rank + 1, c->comm,
-                          c->stream));
-        NCCL_TRY(ncclRecv(row_ptr(c, c->g1), bytes, ncclChar, c->rank + 1, c->comm, c->stream));
+        NCCL_TRY(ncclSend(row_ptr(c, c->g1 - rows), bytes, ncclChar, c->rank + 1, c->comm, st));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g1), bytes, ncclChar, c->rank + 1, c->comm, st));
     }
     NCCL_TRY(ncclGroupEnd());
     return SFL_OK;
@@ -322,6 +335,19 @@ int effective_halo(const sfl_context *c, int fuse)
 }
 
 // ---- poisson_solve executor --------------------------------------------------------------
+// One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
+// all pieces read c->p and write c->p_alt; the caller swaps once per step).
+int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
+                    int g2_begin = 0, int g2_end = 0)
+{
+    if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
+    SFL_TRY(use_device(c));
+    HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div, c->geom,
+                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
+                                  prm, c->opt_sor_rows, c->opt_sor_lane_cells));
+    return SFL_OK;
+}
+
 int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm)
 {
     SFL_TRY(use_device(c));
@@ -337,11 +363,160 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
         ++c->last_launches;
         return SFL_OK;
     }
-    HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div,
-                                  c->geom, st.g_begin, st.g_end, st.nsweeps, st.first_colour, prm,
-                                  c->opt_sor_rows, c->opt_sor_lane_cells));
+    SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end));
     std::swap(c->p, c->p_alt);
-    ++c->last_launches;
+    ++c->last_launches;  // plan steps, not pieces: an overlapped step counts once as well
+    return SFL_OK;
+}
+
+// The exchange stream and its two events (created on first use): the group's when the contexts are
+// linked, the context's own otherwise.
+struct Overlap {
+    hipStream_t compute = nullptr, xstream = nullptr;
+    hipEvent_t ready = nullptr, arrived = nullptr;
+};
+
+int overlap_of(sfl_context *c, Overlap *o)
+{
+    SFL_TRY(use_device(c));
+    hipStream_t *xs = c->group ? &c->group->xstream : &c->xstream;
+    hipEvent_t *e0 = c->group ? &c->group->ev_ready : &c->ev_ready;
+    hipEvent_t *e1 = c->group ? &c->group->ev_arrived : &c->ev_arrived;
+    if (!*xs) HIP_TRY(hipStreamCreateWithFlags(xs, hipStreamNonBlocking));
+    if (!*e0) HIP_TRY(hipEventCreateWithFlags(e0, hipEventDisableTiming));
+    if (!*e1) HIP_TRY(hipEventCreateWithFlags(e1, hipEventDisableTiming));
+    o->compute = c->stream;  // a linked group shares one compute stream
+    o->xstream = *xs;
+    o->ready = *e0;
+    o->arrived = *e1;
+    return SFL_OK;
+}
+
+// Halo exchange off the compute stream: starts once everything issued so far on the compute
+// stream has completed, runs on the exchange stream; `arrived` marks its completion.
+int start_exchange(const std::vector<sfl_context *> &peers, const Overlap &o, int field, int rows)
+{
+    SFL_TRY(use_device(peers[0]));
+    HIP_TRY(hipEventRecord(o.ready, o.compute));
+    HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
+    SFL_TRY(exchange(peers, field, rows, o.xstream));
+    SFL_TRY(use_device(peers[0]));
+    HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+    return SFL_OK;
+}
+
+int await_exchange(const std::vector<sfl_context *> &peers, const Overlap &o)
+{
+    SFL_TRY(use_device(peers[0]));
+    HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
+    return SFL_OK;
+}
+
+// An exchange IN LINE with the compute stream's work.  With RCCL it still travels on the exchange
+// stream -- every operation of a communicator is issued to ONE stream, whatever the operator --
+// bracketed by the two events; in-process copies of a linked group go on the compute stream itself.
+int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows)
+{
+    if (rows <= 0 || ctx->nranks == 1) return SFL_OK;
+    if (!ctx->comm) return exchange(peers, field, rows);
+    Overlap o;
+    SFL_TRY(overlap_of(ctx, &o));
+    SFL_TRY(start_exchange(peers, o, field, rows));
+    return await_exchange(peers, o);
+}
+
+// The fused kernel's program on slabs, with the halo exchanges OVERLAPPED (cut-adjacent
+// rows first, exchange on a second stream).  The plan is unchanged (slab_plan.cpp); what changes
+// is the order in which the rows of two launches are issued around an exchange of H rows:
+//
+//   launch before the exchange    rows [g0, g0+H) and [g1-H, g1) -- what the neighbours will
+//                                 receive -- go first; the exchange starts behind them on the
+//                                 exchange stream; the launch's other rows follow on the compute
+//                                 stream while the halos travel;
+//   launch after the exchange     its rows [g0+ns, g1-ns) need no ghost row (a launch of ns passes
+//                                 reads ns rows beyond its output) and go first; the compute
+//                                 stream then waits for the halos and finishes with the two bands
+//                                 next to the cuts.
+//
+// A slab at the bottom / top of the domain has no neighbour on that side: no band there.  Every
+// piece of a step reads p and writes p_alt (one swap per step), the exchange reads the owned rows
+// of the step's output and writes ghost rows nobody else touches meanwhile, so the pieces are
+// independent and the result is the bits of the plain order.  With SFL_OPT_SOR_OVERLAP = 0, and for
+// the baseline kernel, every step is issued whole on the compute stream.
+int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                           const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm)
+{
+    Overlap o;
+    SFL_TRY(overlap_of(ctx, &o));
+    bool pending = false;  // an exchange is in flight that the next launch's cut-adjacent rows need
+    const size_t n = progs[0].size();
+    for (size_t i = 0; i < n; ++i) {
+        const sfl_plan_step &st0 = progs[0][i];
+        if (st0.kind == SFL_STEP_EXCHANGE) {  // (p exchanges are started by the launch before them)
+            if (pending) SFL_TRY(await_exchange(peers, o));
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows));
+            pending = true;
+            continue;
+        }
+        const bool sends_next = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE &&
+                                progs[0][i + 1].field == SFL_FIELD_PRESSURE;
+        const int send_rows = sends_next ? progs[0][i + 1].rows : 0;
+        const int ns = st0.nsweeps;
+        if (pending) {
+            // rows that need no ghost row first, the cut-adjacent bands behind the exchange
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i];
+                const int lo = c->rank > 0 ? std::min(c->g0 + ns, st.g_end) : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - ns, lo) : st.g_end;
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));
+            }
+            SFL_TRY(await_exchange(peers, o));
+            pending = false;
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i];
+                const int lo = c->rank > 0 ? std::min(c->g0 + ns, st.g_end) : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - ns, lo) : st.g_end;
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end));  // both bands, one launch
+                std::swap(c->p, c->p_alt);
+                ++c->last_launches;
+            }
+            if (sends_next) {  // a one-launch superstep: nothing left to overlap the next exchange with
+                SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, send_rows));
+                pending = true;
+                ++i;
+            }
+            continue;
+        }
+        if (sends_next) {
+            // the rows the neighbours will receive first, then the exchange, then the rest
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i];
+                const int lo = c->rank > 0 ? std::min(c->g0 + send_rows, st.g_end) : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - send_rows, lo) : st.g_end;
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end));  // both bands, one launch
+                std::swap(c->p, c->p_alt);  // the exchange sends from / receives into the step's output
+            }
+            SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, send_rows));
+            pending = true;
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i];
+                const int lo = c->rank > 0 ? std::min(c->g0 + send_rows, st.g_end) : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - send_rows, lo) : st.g_end;
+                std::swap(c->p, c->p_alt);  // back: the remaining rows read the step's input
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));
+                std::swap(c->p, c->p_alt);
+                ++c->last_launches;
+            }
+            ++i;  // the exchange step has been issued
+            continue;
+        }
+        for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+    }
+    if (pending) SFL_TRY(await_exchange(peers, o));
     return SFL_OK;
 }
 
@@ -367,10 +542,12 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         }
         return SFL_OK;
     }
+    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && (ctx->comm || ctx->group))
+        return run_poisson_overlapped(ctx, peers, progs, prm);
     for (size_t i = 0; i < progs[0].size(); ++i) {
         const sfl_plan_step &st0 = progs[0][i];
         if (st0.kind == SFL_STEP_EXCHANGE) {
-            SFL_TRY(exchange(peers, st0.field, st0.rows));
+            SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows));
         } else {
             for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
         }
@@ -624,6 +801,12 @@ int sfl_destroy(sfl_context *c)
         if (st.vel) (void)hipHostFree(st.vel);
         if (st.copied) (void)hipEventDestroy(st.copied);
     }
+    if (c->xstream) {
+        (void)hipStreamSynchronize(c->xstream);
+        (void)hipStreamDestroy(c->xstream);
+    }
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_arrived) (void)hipEventDestroy(c->ev_arrived);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -656,6 +839,9 @@ static int set_option_one(sfl_context *c, int option, int value)
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
+            return SFL_OK;
+        case SFL_OPT_SOR_OVERLAP:
+            c->opt_sor_overlap = value ? 1 : 0;
             return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
@@ -693,6 +879,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
+        case SFL_OPT_SOR_OVERLAP: *value = c->opt_sor_overlap; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -766,6 +953,7 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_sor_lane_cells = z->opt_sor_lane_cells;
         c->opt_sor_halo = z->opt_sor_halo;
         c->opt_fuse_projection = z->opt_fuse_projection;
+        c->opt_sor_overlap = z->opt_sor_overlap;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
@@ -820,7 +1008,7 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure(c, c->vel_tmp, 8, false));
     }
-    SFL_TRY(exchange(peers, SFL_FIELD_VELOCITY, ctx->opt_advect_halo));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, ctx->opt_advect_halo));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
@@ -841,7 +1029,7 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
         SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
-    SFL_TRY(exchange(peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
@@ -861,7 +1049,7 @@ int sfl_calculate_divergence(sfl_context *ctx, float dx)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
     }
-    SFL_TRY(exchange(peers, SFL_FIELD_VELOCITY, 1));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, 1));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
@@ -884,7 +1072,7 @@ int sfl_subtract_gradient(sfl_context *ctx, float dx)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
     }
-    SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, 1));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
@@ -971,8 +1159,8 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
         SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
-    SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, 1));
-    SFL_TRY(exchange(peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));

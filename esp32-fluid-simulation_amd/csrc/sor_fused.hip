@@ -271,8 +271,8 @@ struct Lane4 : WaveCommon {
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads)
-sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t,
-                 SorParams prm)
+sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t1,
+                 sor::Tiling t2, SorParams prm)
 {
     __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
 
@@ -290,8 +290,13 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         const int xcd = block & 7, idx = block >> 3;
         block = xcd * per + min(xcd, rem) + idx;  // bijective for every nblocks
     }
-    const int tile = block * kWavesPerBlock + wave;
-    if (tile >= t.n_tiles) return;
+    // a launch covers up to two row ranges (the two cut-adjacent bands of a slab in one launch):
+    // the tiles of the second tiling follow those of the first
+    int tile = block * kWavesPerBlock + wave;
+    if (tile >= t1.n_tiles + t2.n_tiles) return;
+    const bool second = tile >= t1.n_tiles;  // wave-uniform
+    const sor::Tiling t = second ? t2 : t1;
+    if (second) tile -= t1.n_tiles;
     const sor::TileRect rect = sor::tile_rect(t, tile);
     const int x0 = sor::strip_x0(t, rect.strip);
     const int r0 = rect.r0, r1 = rect.r1;
@@ -397,31 +402,40 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                          int g_begin, int g_end, SorParams prm, int rows_per_chunk)
+                          SorRows rows, SorParams prm, int rows_per_chunk)
 {
-    const int rpc = rows_per_chunk > 0
-                        ? rows_per_chunk
-                        : auto_rows_per_chunk<B>(g, g_begin, g_end, NS,
-                                                 resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
-    const sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                           g_end, rpc, sor::kEdgeRowCost16);
-    const int blocks = (t.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t, prm);
+    auto tiling = [&](int g_begin, int g_end) {
+        if (g_end <= g_begin) {
+            sor::Tiling none{};
+            none.n_tiles = 0;
+            return none;
+        }
+        int rpc = rows_per_chunk > g_end - g_begin ? g_end - g_begin : rows_per_chunk;
+        if (rpc <= 0)
+            rpc = auto_rows_per_chunk<B>(g, g_begin, g_end, NS, resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
+        return sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin, g_end, rpc,
+                                sor::kEdgeRowCost16);
+    };
+    const sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
+    const int tiles = t1.n_tiles + t2.n_tiles;
+    if (tiles == 0) return hipSuccess;
+    const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm);
     return hipGetLastError();
 }
 
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     int g_begin, int g_end, SorParams prm, int rows_per_chunk)
+                     SorRows rows, SorParams prm, int rows_per_chunk)
 {
     if (prm.dx == 1.0f)
-        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+    return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
 }
 
 template <int NS, bool ZERO_IN>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                       int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
+                       SorRows rows, SorParams prm, int rows_per_chunk, int lane_cells)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
@@ -431,19 +445,19 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     // than the packed one at every fuse depth on 8192^2 (profiles/r01_*); packed is opt-in
     if (lane_cells == 0) lane_cells = 2;
     if (lane_cells == 4 && can4)
-        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
     if (can2v)
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk);
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
 }
 
 template <int NS>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     int g_begin, int g_end, SorParams prm, int rows_per_chunk, int lane_cells)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int lane_cells)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
 }
 
 }  // namespace
@@ -455,14 +469,14 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 #endif
 #define SFL_DEFINE_NS(N)                                                                          \
     hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
-                                      Slab g, int g_begin, int g_end, SorParams prm,              \
+                                      Slab g, SorRows rows, SorParams prm,                        \
                                       int rows_per_chunk, int lane_cells)                         \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells); \
+        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells); \
     }
 #define SFL_DECLARE_NS(N)                                                                         \
     hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
-                                      Slab g, int g_begin, int g_end, SorParams prm,              \
+                                      Slab g, SorRows rows, SorParams prm,                        \
                                       int rows_per_chunk, int lane_cells);
 SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
 SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
@@ -487,17 +501,16 @@ SFL_DEFINE_NS(16)
 
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
-                            Slab g, int g_begin, int g_end, int nsweeps, int first_colour,
+                            Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells)
 {
-    if (g_end <= g_begin) return hipSuccess;
+    if (rows.g_end <= rows.g_begin && rows.g2_end <= rows.g2_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
         p_out == p_in || p_out == nullptr || d == nullptr ||
         (lane_cells != 0 && lane_cells != 2 && lane_cells != 4))
         return hipErrorInvalidValue;
-    if (rows_per_chunk > g_end - g_begin) rows_per_chunk = g_end - g_begin;
 #define SFL_CASE(N) \
-    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, g_begin, g_end, prm, rows_per_chunk, lane_cells);
+    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }

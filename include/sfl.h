@@ -73,6 +73,11 @@ extern "C" {
                                      inside the dye-advection kernel (one pass over v), 0 = two
                                      kernels                                                     */
 
+#define SFL_OPT_SOR_OVERLAP 8     /* slabs, kernel 2: 1 (default) = the halo exchanges of a solve run
+                                     on a second stream, overlapped with the rows of the
+                                     neighbouring launches that do not depend on them (cut-adjacent
+                                     rows first / last); 0 = every launch whole, exchanges in line */
+
 typedef struct sfl_context sfl_context;
 
 /* =====================================================================================

@@ -617,3 +617,64 @@ def test_group_options_are_group_wide(sfl, oracle):
         for s in slabs:
             s.close()
     assert_bit_equal(got, want, "advection with a group-wide 12-row halo")
+
+
+@pytest.mark.parametrize("nranks,dim_y,fuse,halo,iters", [(2, 400, 8, 16, 21), (3, 600, 12, 24, 30), (4, 512, 6, 6, 9),
+                                                          (4, 1024, 8, 64, 40), (8, 1024, 12, 36, 40), (2, 96, 16, 32, 20)])
+def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y, fuse, halo, iters):
+    """SURVEY 8e overlap: the halo exchanges of a solve run on a second stream while the rows of the
+    neighbouring launches that do not depend on them are relaxed (cut-adjacent rows first / last).
+    Virtual ranks on one GPU (in-process copies on the exchange stream): overlapped and in-line
+    execution must both reproduce the oracle, with the same launch / exchange counts."""
+    dim_x = 640
+    rng = np.random.default_rng(nranks * 100 + fuse)
+    d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    infos = []
+    for overlap in (1, 0):
+        slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+        try:
+            sfl.Solver.link_group(slabs)
+            slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
+            slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
+            for s in slabs:
+                s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+            for _ in range(2):      # twice: the second solve starts while nothing of the first is pending
+                slabs[0].poisson_solve(1.0, iters, OMEGA)
+            slabs[0].synchronize()
+            infos.append(slabs[nranks // 2].last_solve_info())
+            got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+        finally:
+            for s in slabs:
+                s.close()
+        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}")
+    assert infos[0] == infos[1] and infos[0]["exchanges"] > 0
+
+
+def test_overlapped_exchange_inside_a_full_step(sfl, oracle):
+    """The whole sim step on four virtual ranks with overlapped solve exchanges, several steps in a
+    row (buffers ping-pong across steps), against the oracle."""
+    dim_x, dim_y, iters, nranks = 256, 480, 14, 4
+    v, c, _ = random_fields(dim_x, dim_y, 77, 50.0)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 6)
+        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, 12)
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, 8)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        vo, co = v, c
+        for step in range(3):
+            slabs[0].step(DT, 1.0, iters, OMEGA)
+            vo, do, po, co = oracle.step(vo, co, DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), vo, "velocity after 3 steps")
+        assert_bit_equal(cat(sfl.capi.FIELD_PRESSURE), po, "pressure after 3 steps")
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), co, "colour after 3 steps")
+    finally:
+        for s in slabs:
+            s.close()
