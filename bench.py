@@ -23,8 +23,9 @@ Output: ONE JSON line on rank 0 (contract in the task statement), including
   parity        the pressure field left by the LAST TIMED solve, downloaded and compared bit for
                 bit with the reference CPU loop run on the very same right-hand side (downloaded
                 from the GPU); the process exits non-zero on a mismatch
-  roofline      the bound that binds the temporally blocked kernel (VALU issue), the measured HBM
-                traffic fraction, and the SURVEY 8d algorithmic-bytes figure (labelled as a ratio)
+  roofline      the bound that binds the temporally blocked kernel (the pass over HBM: bytes really
+                moved, from the committed PMC passes, / launch duration by HIP events), the VALU
+                fraction beside it, and the SURVEY 8d algorithmic-bytes figure (labelled as a ratio)
   cpu_baseline  the reference's own CPU loop (oracle/_ref, or the oracle port) on this host,
                 1 thread: the parity solve itself is the timed sample; N = 1 only
 """
@@ -449,37 +450,47 @@ def run_rank(args):
         algorithmic_gbs = bytes_per_launch / avg_launch_s / 1e9
         name, cus, mem = sfl.device_info(local_rank)
         pmc = pmc_record((size, dim_y), info["fuse"], world)
-        # VALU roofline: the reference's 8 individually rounded fp32 operations per relaxation
-        # (poisson.cpp:63-112; contraction to FMA would change results) against the rate at which the
-        # chip issues such operations.  Measured on gfx950 (tools/ubench_pk_chain.hip,
-        # profiles/r02_twin_tiles_experiment.txt): a plain fp32 VALU instruction of a wave64 issues
-        # every ~2.35 cycles per SIMD, a packed one every ~4.6 -- the same operation rate either way.
+        # What binds the temporally blocked kernel is the pass over memory (every
+        # depth NS <= 12 takes the same ~180 us per launch at 8192^2): `achieved` = HBM bytes the
+        # launch really moves / its duration, the bytes from the committed rocprofv3 PMC passes when
+        # one matches this configuration, else the compulsory 12 B per cell (p in, rhs in, p out).
+        traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+        compulsory = 12.0 * cells / world
+        moved = traffic if traffic else compulsory
+        hbm_gbs = moved / avg_launch_s / 1e9
+        # VALU side: the reference's 8 individually rounded fp32 operations per relaxation
+        # (poisson.cpp:63-112; contraction to FMA would change results) against half of the chip's
+        # fp32 vector peak (an FMA counts two): a plain wave64 instruction issues every 2 cycles per
+        # SIMD, measured (profiles/r02_ubench_pk_chain.log).
         valu_peak = cus * 4 * VALU_LANES_PER_SIMD_CLK * VALU_CLOCK_GHZ / 1e3
         valu_achieved = value / world * SOR_FLOPS_PER_CELL_ITER / 1e12
-        traffic = pmc["traffic_bytes_per_launch"] if pmc else None
+        useful_insts = SOR_FLOPS_PER_CELL_ITER * (cells / world) * iters / launches / 64
         roofline = {
-            "bound": "valu", "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
-            "frac": valu_achieved / valu_peak,
-            "peak_definition": f"{cus} CUs x 4 SIMDs x {VALU_LANES_PER_SIMD_CLK} fp32 lanes per clock x "
-                               f"{VALU_CLOCK_GHZ} GHz = half of the chip's 157.3 TFLOP/s fp32 vector peak "
-                               "(an FMA counts two; the reference rounds every product and sum, so no FMA); a "
-                               "wave64 instruction issues every 2 cycles (profiles/r02_ubench_pk_chain.log)",
-            "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
-            "avg_launch_us": avg_launch_s * 1e6,
+            "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": hbm_gbs / HBM_PEAK_GBS,
+            "achieved_definition": ("HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE) / "
+                                    "launch duration by HIP events" if traffic else
+                                    "compulsory 12 B per cell per launch (no PMC pass committed for this "
+                                    "configuration) / launch duration by HIP events"),
             "traffic": traffic,
             "traffic_source": pmc["source"] if pmc else None,
-            "hbm_traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "issued_over_useful": (pmc["valu_wave_insts_per_launch"] * 64
-                                   / (SOR_FLOPS_PER_CELL_ITER * (cells / world) * iters / launches))
-            if pmc and pmc.get("valu_wave_insts_per_launch") else None,
+            "compulsory_bytes_per_launch": compulsory,
+            "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
+            "avg_launch_us": avg_launch_s * 1e6,
             # SURVEY 8d's figure for an UNFUSED sweep (16 B per cell-iteration); a temporally blocked
             # kernel moves a fraction of it, so this is a ratio, not a fraction of a roofline
             "algorithmic": {"bytes_per_cell_iter": SOR_BYTES_PER_CELL_ITER,
                             "bytes_per_launch": bytes_per_launch, "GBps": algorithmic_gbs,
-                            "hbm_peak_GBps": HBM_PEAK_GBS,
                             "algorithmic_vs_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
                             "note": "ratio of unfused-sweep bytes to the HBM peak, > 1 by temporal "
                                     "blocking; not a roofline fraction"},
+            "valu": {"flops_per_cell_iter": SOR_FLOPS_PER_CELL_ITER, "achieved": valu_achieved,
+                     "peak": valu_peak, "unit": "TFLOP/s", "frac": valu_achieved / valu_peak,
+                     "peak_definition": f"{cus} CUs x 4 SIMDs x {VALU_LANES_PER_SIMD_CLK} fp32 lanes per clock x "
+                                        f"{VALU_CLOCK_GHZ} GHz = half of the 157.3 TFLOP/s fp32 vector peak (no "
+                                        "FMA: the reference rounds every product and sum)",
+                     "issued_over_useful": (pmc["valu_wave_insts_per_launch"] / useful_insts)
+                     if pmc and pmc.get("valu_wave_insts_per_launch") else None},
         }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",

@@ -678,3 +678,27 @@ def test_overlapped_exchange_inside_a_full_step(sfl, oracle):
     finally:
         for s in slabs:
             s.close()
+
+
+def test_baseline_config5_slab_program_vs_oracle(sfl, oracle):
+    """BASELINE config 5's per-GPU program (16384 columns, 2048-row slabs, 200 SOR iterations, every
+    option on auto: fuse 16, 64-row supersteps, six overlapped p exchanges + the rhs exchange) on
+    two neighbouring virtual ranks -- a 16384 x 4096 domain -- against the oracle, every cell."""
+    dim_x, dim_y, iters, nranks = 16384, 4096, 200, 2
+    rng = np.random.default_rng(55)
+    d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[1].last_solve_info()
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert info["fuse"] == 16 and info["launches"] == 25 and info["exchanges"] == 7
+    assert_bit_equal(got, want, "C5 slab program: 16384 x 4096 in two slabs, 200 iterations")
