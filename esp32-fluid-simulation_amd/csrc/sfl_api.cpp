@@ -303,19 +303,19 @@ sfl::SorParams sor_params(float dx, float omega)
     return prm;
 }
 
-// Fuse depth: explicit option, or auto from the slab size.  Measured on MI355X with the balanced
-// tiling (profiles/r01_rows_per_chunk.txt, ms per 80-iteration solve, fuse 8 / 12 / 16):
-// 8192 x 8192: 3.6 / 2.7 / 2.15; 8192 x 4096: 1.79 / 1.40 / 1.29; 8192 x 2048: 0.84 / 0.75 / 0.75;
-// 8192 x 1024: 0.51 / 0.50 / 0.51 (0.48 at 10); 8192 x 512: 0.39 / 0.42 / 0.45; 2048^2 (40 iterations):
-// 0.19 / 0.21 / 0.23.  Big slabs are VALU / HBM bound and want the deepest fusion; small ones are
-// dominated by the 2 * NS warm-up rows each tile re-streams.  Every rank of a group sees the same
-// thinnest slab, so all ranks resolve the same value.
+// Fuse depth: explicit option, or auto from the slab size.  Measured on MI355X, ms per 80-iteration
+// solve at fuse 8 / 10 / 12 / 14 / 16 (round 2, gpurun_out/r02_run13-14, auto rows per tile):
+// 8192 x 8192: 3.6 / 3.0 / 2.51 / 2.39 / 1.95; 8192 x 4096: - / - / 1.26 / 1.14 / 1.08; 8192 x 2048: - / 0.70 /
+// 0.64 / 0.60 / 0.60; 8192 x 1024: 0.458 / 0.398 / 0.425 / 0.57 / 0.64; 8192 x 512 (round 1): 0.39 / - / 0.42 /
+// - / 0.45; 2048^2 (40 iterations, round 1): 0.19 / - / 0.21 / - / 0.23.  Big slabs are bound by the pass over memory
+// each launch makes and want the deepest fusion; small ones by the 2 * NS warm-up rows each tile
+// re-streams.  Every rank of a group sees the same thinnest slab, so all ranks resolve the same value.
 int effective_fuse(const sfl_context *c)
 {
     int f = c->opt_sor_fuse;
     if (f == 0) {
         const int64_t cells = (int64_t)min_owned_rows(c) * c->dim_x;
-        f = cells >= 12000000 ? 16 : cells >= 6000000 ? 12 : 8;
+        f = cells >= 12000000 ? 16 : cells >= 6000000 ? 10 : 8;
     }
     if (f < 2) f = 2;
     if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
