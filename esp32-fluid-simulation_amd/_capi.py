@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libsfl_hip.so")
+# SFL_LIB: an alternative build of the same library (A/B experiments with compile-time variants)
+LIB_PATH = os.environ.get("SFL_LIB") or os.path.join(_PKG, "lib", "libsfl_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_RCCL, ERR_NOMEM, ERR_STATE, ERR_HALO = 0, -1, -2, -3, -4, -5, -6
 FIELD_VELOCITY, FIELD_COLOR, FIELD_DIVERGENCE, FIELD_PRESSURE = 0, 1, 2, 3

@@ -73,8 +73,7 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 // result for the global rows of `rows` to p_out (p_out must not alias p_in).  Needs p_in
 // valid on rows [g_begin - nsweeps, g_end + nsweeps) and d on one row less each side, clipped
 // to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).  lane_cells =
-// cells per lane: 2 (scalar fp32, any dim_x), 4 (packed fp32, dim_x % 4 == 0 and 16-byte aligned
-// arrays; silently falls back to 2 otherwise) or 0 (auto).
+// cells per lane: 2, or 0 (auto = 2); kept as a parameter for the option it serves.
 // One launch covers output rows [g_begin, g_end) and, optionally, a second disjoint range
 // [g2_begin, g2_end) (the two cut-adjacent bands of a slab around a halo exchange in ONE launch).
 #define SFL_MAX_FUSE 16

@@ -849,8 +849,9 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_sor_halo = value;
             return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS:
-            if (value != 0 && value != 2 && value != 4)
-                return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto), 2 or 4");
+            if (value != 0 && value != 2)
+                return fail(SFL_ERR_INVALID, "cells per lane must be 0 (auto) or 2 (the packed 4-cell "
+                            "flavour of round 1 is gone: never faster)");
             c->opt_sor_lane_cells = value;
             return SFL_OK;
     }

@@ -3,15 +3,12 @@
 // neighbours with DPP wave shifts, S / N neighbours stay in VGPRs, the right-hand side waits in
 // a per-lane LDS ring.  No barriers, no atomics, no MFMA: a bandwidth / VALU-issue bound stencil.
 //
-// Two lane flavours:
-//   Lane2  2 cells per lane, V = float, 128-column tiles, 4- or 8-byte accesses; works for every
-//          dim_x (odd widths use dword accesses) -- the general path
-//   Lane4  4 cells per lane, V = 2 packed floats, 256-column tiles, 16-byte accesses, every
-//          relaxation in packed fp32 (v_pk_add_f32 / v_pk_mul_f32): twice the arithmetic
-//          throughput, half the tile overlap; needs dim_x % 4 == 0 and 16-byte aligned arrays
+// One lane flavour: 2 cells per lane, V = float, 128-column tiles, 8-byte accesses where dim_x is even
+// and the arrays are 8-byte aligned, 4-byte ones otherwise (any dim_x).  (Round 1 also carried a
+// 4-cells-per-lane flavour on packed fp32; packed fp32 issues at half the rate of plain fp32 on
+// gfx950 -- profiles/r02_experiments_without_gain.txt -- it was never faster and is gone.)
 //
-// Compiled with -ffp-contract=off (bit-exactness contract, see stencil_kernels.hip); packed
-// add / mul round each component separately, exactly like the scalar instructions.
+// Compiled with -ffp-contract=off (bit-exactness contract, see stencil_kernels.hip).
 #include "kernels.h"
 #include "sor_stream_core.h"
 
@@ -19,12 +16,11 @@ namespace sfl {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+constexpr size_t kNtStoreCells = 24u << 20;  // local cells from which p is stored non-temporally
 constexpr int kThreads = 64 * kWavesPerBlock;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
-typedef int v4i __attribute__((ext_vector_type(4)));
 
 // DPP full-wave shifts (GFX9 wave_shr:1 / wave_shl:1).  Lane 0 / lane 63 receive 0, which only
 // ever feeds cells of the tile's invalid rim.
@@ -68,7 +64,12 @@ struct WaveCommon {
 
 // ---- 2 cells per lane --------------------------------------------------------------------
 // VEC: dim_x even and 8-byte aligned arrays -> one 8-byte access per lane and row.
-template <int NS, bool VEC, bool ZERO_IN>
+// NT (VEC only): the finished rows are stored non-temporally.  A launch writes every p row once and
+// reads it back a whole launch later: on slabs whose arrays exceed the caches the nt hint keeps the
+// write stream from displacing the halo rows neighbouring tiles are about to re-read (8192^2:
+// -1.1 %, 8192 x 4096: -2.3 .. -5 %); on cache-resident slabs the next launch WANTS those rows in
+// cache (8192 x 1024: +9 %), so the launcher sets it from the slab size.
+template <int NS, bool VEC, bool ZERO_IN, bool NT = false>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
@@ -153,7 +154,7 @@ struct Lane2 : WaveCommon {
                 v2f o;
                 o.x = a;
                 o.y = b;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, NT ? 2 : 0);
             }
         } else {
             if (a_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a), rs_out, off_out, soff, 0);
@@ -163,102 +164,6 @@ struct Lane2 : WaveCommon {
 
     // ring: [RING slots][2 planes][64 lanes]; slot and plane are compile-time constants at
     // every call site, so each access is one DS instruction with an immediate offset
-    __device__ __forceinline__ void ring_store(int slot, int plane, V x) const
-    {
-        ring[(slot * 2 + plane) * 64] = x;
-    }
-    __device__ __forceinline__ V ring_load(int slot, int plane) const
-    {
-        return ring[(slot * 2 + plane) * 64];
-    }
-};
-
-// ---- 4 cells per lane, packed fp32 ----------------------------------------------------------
-struct Mask2 {
-    bool x, y;
-};
-
-template <int NS, bool ZERO_IN>
-struct Lane4 : WaveCommon {
-    using V = v2f;
-    using M = Mask2;
-    static constexpr int kTileCols = 256, kColAlign = 4, kCells = 4, kPrefetch = 3;
-    static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 128;
-
-    v2f *ring;        // this lane's pair of ring slot 0 / plane 0 in LDS
-    int off_in;       // byte offset of the clamped load column of the lane's first cell
-    int off_out;      // byte offset of its true column
-    bool quad_out;    // the lane's four columns lie in the tile's exact interior and the domain
-
-    __device__ __forceinline__ void setup(float *ring_base, int lane, int x0, int halo)
-    {
-        ring = reinterpret_cast<v2f *>(ring_base) + lane;
-        const int xq = x0 + 4 * lane;  // multiple of 4; dim_x % 4 == 0: quad inside or outside
-        off_in = 4 * min(max(xq, 0), dim_x - 4);
-        off_out = 4 * xq;
-        quad_out = xq >= 0 && xq < dim_x && xq >= x0 + halo && xq < x0 + kTileCols - halo;
-    }
-    // which = 0: cells a = columns {xq, xq + 2}; which = 1: cells b = {xq + 1, xq + 3}
-    __device__ __forceinline__ sor::EdgeCell<Lane4> edge_cell(int lane, int x0, int which) const
-    {
-        sor::EdgeCell<Lane4> ec;
-        const float k2 = (float)(-1.0 / 2.0), k3 = (float)(-1.0 / 3.0), k4 = -0.25f;
-        float kf[2], kp[2], zf[2];
-        bool in[2];
-        for (int c = 0; c < 2; ++c) {
-            const int x = x0 + 4 * lane + which + 2 * c;
-            const int nh = (x > 0 ? 1 : 0) + (x < dim_x - 1 ? 1 : 0);
-            in[c] = x >= 0 && x < dim_x;
-            kf[c] = (nh == 2) ? k4 : (nh == 1) ? k3 : k2;
-            kp[c] = (nh == 2) ? k3 : k2;
-            zf[c] = (nh == 2) ? -0.0f : 0.0f;
-        }
-        ec.in = {in[0], in[1]};
-        ec.k_full = v2f{kf[0], kf[1]};
-        ec.k_part = v2f{kp[0], kp[1]};
-        ec.z_full = v2f{zf[0], zf[1]};
-        return ec;
-    }
-
-    __device__ __forceinline__ V splat(float x) const { return v2f{x, x}; }
-    __device__ __forceinline__ V select(M m, V a, V b) const
-    {
-        return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y};
-    }
-    __device__ __forceinline__ M mask_and(M m, bool row) const { return {m.x && row, m.y && row}; }
-    // colour vector shifted by one position: {previous lane's .y, own .x} / {own .y, next lane's .x}
-    __device__ __forceinline__ V from_lower_lane(V v) const { return v2f{lane_below(v.y), v.x}; }
-    __device__ __forceinline__ V from_upper_lane(V v) const { return v2f{v.y, lane_above(v.x)}; }
-    __device__ __forceinline__ V detach(V v) const
-    {
-        V r;
-        asm("v_mov_b32 %0, %1" : "=v"(r.x) : "v"(v.x));
-        asm("v_mov_b32 %0, %1" : "=v"(r.y) : "v"(v.y));
-        return r;
-    }
-
-    __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
-    {
-        const int soff = load_row_bytes(r);
-        const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_d, off_in, soff, 0));
-        da = v2f{f.x, f.z};
-        db = v2f{f.y, f.w};
-        if (!ZERO_IN) {
-            const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_p, off_in, soff, 0));
-            pa = v2f{q.x, q.z};
-            pb = v2f{q.y, q.w};
-        }
-    }
-
-    __device__ __forceinline__ void store_row(int r, V a, V b) const
-    {
-        if (quad_out) {
-            const v4f o = {a.x, b.x, a.y, b.y};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, o), rs_out, off_out, row_bytes(r), 0);
-        }
-    }
-
-    // ring: [RING slots][2 planes][64 lanes] of float pairs (8-byte DS accesses, conflict free)
     __device__ __forceinline__ void ring_store(int slot, int plane, V x) const
     {
         ring[(slot * 2 + plane) * 64] = x;
@@ -439,15 +344,13 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
-    const bool can4 = (g.dim_x % 4 == 0) && (all & 15) == 0 && g.dim_x >= 4;
     const bool can2v = (g.dim_x % 2 == 0) && (all & 7) == 0;
-    // auto: the scalar flavour (4 waves / SIMD at fuse 8..12, 3 at 16) measured equal or faster
-    // than the packed one at every fuse depth on 8192^2 (profiles/r01_*); packed is opt-in
-    if (lane_cells == 0) lane_cells = 2;
-    if (lane_cells == 4 && can4)
-        return launch_dx<Lane4<NS, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
-    if (can2v)
+    if (can2v) {
+        // non-temporal stores once the slab's arrays no longer fit the caches (see Lane2)
+        if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
+            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
         return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+    }
     return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
 }
 
@@ -507,7 +410,7 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
     if (rows.g_end <= rows.g_begin && rows.g2_end <= rows.g2_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
         p_out == p_in || p_out == nullptr || d == nullptr ||
-        (lane_cells != 0 && lane_cells != 2 && lane_cells != 4))
+        (lane_cells != 0 && lane_cells != 2))
         return hipErrorInvalidValue;
 #define SFL_CASE(N) \
     case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);

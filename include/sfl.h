@@ -64,8 +64,8 @@ extern "C" {
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
                                      1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link)  */
-#define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto, 2 = scalar fp32 (any
-                                     width), 4 = packed fp32 (dim_x % 4 == 0; else falls back)    */
+#define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto or 2 (the only flavour
+                                     left: round 1's packed 4-cell tiles were never faster)        */
 #define SFL_OPT_SOR_HALO 6        /* rows of p exchanged per superstep on a slab (kernel 2): 0 =
                                      auto (64 on slabs of >= 1024 rows, else 32), else fuse..64;
                                      larger = fewer, larger exchanges, more recomputed ghost rows */

@@ -14,11 +14,13 @@ root = sys.argv[1]
 
 def short(name):
     import re
-    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+), (?:(true|false), )?(true|false)>, \d+, (true|false), (true|false)(?:, (true|false))?>", name)
+    # sor_fused_kernel<Lane2<NS, VEC, ZERO_IN[, NT]> | Lane4<NS, ZERO_IN>, NS, DX1, ZERO_IN>
+    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)>, \d+, (true|false), (true|false)>", name)
     if m:
-        flavour = "Twin" if m.group(7) == "true" else f"Lane{m.group(1)}"
-        return (f"sor_fused_kernel<{flavour}, NS={m.group(2)}, dx1={m.group(5)}, "
-                f"zero_in={m.group(6)}>")
+        flags = [f == "true" for f in re.findall(r"true|false", m.group(3))]
+        nt = m.group(1) == "2" and len(flags) >= 3 and flags[2]
+        return (f"sor_fused_kernel<Lane{m.group(1)}{'nt' if nt else ''}, NS={m.group(2)}, dx1={m.group(4)}, "
+                f"zero_in={m.group(5)}>")
     for key in ("divergence_stream_kernel", "gradient_stream_kernel", "sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
                 "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):
         if key in name:

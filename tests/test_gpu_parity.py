@@ -69,24 +69,6 @@ def test_sor_fused_vs_oracle(sfl, oracle, dim_x, dim_y):
                      oracle.poisson_solve(d, 0.5, 5, np.float32(1.3)), "dx 0.5 omega 1.3")
 
 
-LANE4_SHAPES = [(4, 4), (8, 3), (64, 48), (128, 64), (256, 40), (260, 70), (512, 96), (1024, 50), (1500, 33)]
-
-
-@pytest.mark.parametrize("dim_x,dim_y", LANE4_SHAPES)
-def test_sor_fused_packed_lane4_vs_oracle(sfl, oracle, dim_x, dim_y):
-    """4 cells per lane, packed fp32 (v_pk_add_f32 / v_pk_mul_f32): same bits as the scalar path."""
-    _, _, d = random_fields(dim_x, dim_y, 4)
-    for fuse, iters, rows in [(2, 1, 0), (4, 3, 16), (8, 4, 0), (8, 9, 24), (16, 8, 0), (6, 7, 0),
-                              (12, 6, 0), (14, 7, 20), (10, 5, 0)]:
-        hp = sfl.HostPath(sor_kernel=2, sor_fuse=fuse, sor_rows=rows, sor_lane_cells=4)
-        assert_bit_equal(hp.poisson_solve(d, 1.0, iters, OMEGA),
-                         oracle.poisson_solve(d, 1.0, iters, OMEGA),
-                         f"lane4 {dim_x}x{dim_y} fuse {fuse} iters {iters}")
-    hp = sfl.HostPath(sor_kernel=2, sor_fuse=8, sor_lane_cells=4)
-    assert_bit_equal(hp.poisson_solve(d, 0.5, 5, np.float32(1.3)),
-                     oracle.poisson_solve(d, 0.5, 5, np.float32(1.3)), "lane4 dx 0.5 omega 1.3")
-
-
 @pytest.mark.parametrize("dim_x,dim_y", SHAPES)
 def test_operators_vs_oracle(hip, oracle, dim_x, dim_y):
     for seed, vamp in [(1, 100.0), (2, 1000.0), (3, 0.0)]:
@@ -227,13 +209,13 @@ def bench_rhs(sfl, size, dim_y=None):
 
 def test_headline_size_spot_check_vs_oracle(sfl, oracle):
     """8192 x 8192 (BASELINE config 3 grid), 16 iterations = 32 colour passes: two launches of the
-    NS = 16 kernel (the second continues from a given p: the instantiation bench.py times), both
-    lane flavours and a shallower depth, every cell against the oracle (SURVEY 8d parity gate)."""
+    NS = 16 kernel (the second continues from a given p: the instantiation bench.py times) and two
+    shallower depths, every cell against the oracle (SURVEY 8d parity gate)."""
     n, iters = 8192, 16
     rng = np.random.default_rng(2026)
     d = (rng.standard_normal((n, n)) * 0.05).astype(np.float32)
     want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
-    for lane, fuse in ((2, 16), (2, 12), (4, 16)):
+    for lane, fuse in ((2, 16), (2, 12), (0, 8)):
         with sfl.Solver(n, n) as s:
             s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
             s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
@@ -284,7 +266,7 @@ def test_baseline_config2_vs_oracle(sfl, oracle):
 
 def test_large_grid_properties(sfl):
     """16384 x 16384 (BASELINE config 5 grid): size-independent properties instead of an oracle
-    run -- (1) the fused kernel (any fuse depth, either lane flavour) and the one-launch-per-pass
+    run -- (1) the fused kernel (any fuse depth) and the one-launch-per-pass
     baseline kernel are different programs that must agree bit for bit; (2) a zero right-hand
     side keeps the pressure at (signed) zero; (3) the solve is deterministic."""
     n, iters = 16384, 3
@@ -293,7 +275,7 @@ def test_large_grid_properties(sfl):
         d = (rng.standard_normal((n, n)) * 0.1).astype(np.float32)
         s.upload(sfl.capi.FIELD_DIVERGENCE, d)
         results = []
-        for kernel, fuse, lane in ((1, 0, 0), (2, 6, 2), (2, 16, 2), (2, 4, 4), (2, 6, 2)):
+        for kernel, fuse, lane in ((1, 0, 0), (2, 6, 2), (2, 16, 2), (2, 4, 0), (2, 6, 2)):
             s.set_option(sfl.capi.OPT_SOR_KERNEL, kernel)
             if fuse:
                 s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
@@ -331,7 +313,7 @@ def test_api_error_paths(sfl):
     cap = sfl.capi
     with sfl.Solver(32, 16) as s:
         for opt, bad in ((cap.OPT_SOR_KERNEL, 3), (cap.OPT_SOR_FUSE, 7), (cap.OPT_SOR_FUSE, 18),
-                         (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_ADVECT_HALO, 0), (cap.OPT_SOR_HALO, 1),
+                         (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_SOR_LANE_CELLS, 4), (cap.OPT_ADVECT_HALO, 0), (cap.OPT_SOR_HALO, 1),
                          (99, 0)):
             with pytest.raises(sfl.SflError) as e:
                 s.set_option(opt, bad)
@@ -379,11 +361,11 @@ def test_randomised_configurations_vs_oracle(sfl, oracle):
         dim_x = int(rng.integers(2, 400))
         dim_y = int(rng.integers(2, 300))
         if case % 4 == 0:
-            dim_x = int(rng.choice([4, 8, 128, 256, 260, 512, 640]))
+            dim_x = int(rng.choice([4, 8, 128, 256, 260, 512, 640, 1500]))
         iters = int(rng.integers(1, 14))
         fuse = int(rng.choice([2, 4, 6, 8, 10, 12, 14, 16]))
         rows = int(rng.choice([0, 0, 8, 17, 40]))
-        lane = int(rng.choice([2, 4]))
+        lane = int(rng.choice([0, 2]))
         dx = float(rng.choice([1.0, 1.0, 0.5, 2.0]))
         omega = np.float32(rng.choice([1.96, 1.0, 1.7]))
         nranks = int(rng.choice([1, 1, 2, 3]))
