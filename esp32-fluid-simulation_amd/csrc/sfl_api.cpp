@@ -307,7 +307,9 @@ sfl::SorParams sor_params(float dx, float omega)
 // solve at fuse 8 / 10 / 12 / 14 / 16 (round 2, gpurun_out/r02_run13-14, auto rows per tile):
 // 8192 x 8192: 3.6 / 3.0 / 2.51 / 2.39 / 1.95; 8192 x 4096: - / - / 1.26 / 1.14 / 1.08; 8192 x 2048: - / 0.70 /
 // 0.64 / 0.60 / 0.60; 8192 x 1024: 0.458 / 0.398 / 0.425 / 0.57 / 0.64; 8192 x 512 (round 1): 0.39 / - / 0.42 /
-// - / 0.45; 2048^2 (40 iterations, round 1): 0.19 / - / 0.21 / - / 0.23.  Big slabs are bound by the pass over memory
+// - / 0.45; 40 iterations: 4096^2 - / 0.343 / 0.327 / 0.308 / 0.294; 3072^2 0.245 / 0.208 / 0.223 / 0.294 / 0.297; 2048^2
+// 0.155 / 0.143 / 0.175 / - / 0.217; 1024^2 0.086 / 0.090 / 0.097; 8192 x 768 (80): 0.366 / 0.333 / 0.393; 8192 x 512: 0.303 /
+// 0.305 / 0.350.  Big slabs are bound by the pass over memory
 // each launch makes and want the deepest fusion; small ones by the 2 * NS warm-up rows each tile
 // re-streams.  Every rank of a group sees the same thinnest slab, so all ranks resolve the same value.
 int effective_fuse(const sfl_context *c)
@@ -315,7 +317,7 @@ int effective_fuse(const sfl_context *c)
     int f = c->opt_sor_fuse;
     if (f == 0) {
         const int64_t cells = (int64_t)min_owned_rows(c) * c->dim_x;
-        f = cells >= 12000000 ? 16 : cells >= 6000000 ? 10 : 8;
+        f = cells >= 12000000 ? 16 : cells >= 3000000 ? 10 : 8;
     }
     if (f < 2) f = 2;
     if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;

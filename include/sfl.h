@@ -59,7 +59,7 @@ extern "C" {
 #define SFL_OPT_SOR_KERNEL 0      /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
                                      2 = fused multi-pass streaming kernel                       */
 #define SFL_OPT_SOR_FUSE 1        /* colour passes fused per launch by kernel 2: even, 2..16, or
-                                     0 = auto (16 on slabs of >= 12 M cells, 10 from 6 M, else 8) */
+                                     0 = auto (16 on slabs of >= 12 M cells, 10 from 3 M, else 8) */
 #define SFL_OPT_ADVECT_HALO 2     /* rows of advected-field halo kept per side on a slab (>= 1)  */
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),

@@ -497,7 +497,7 @@ def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
 
 @pytest.mark.parametrize("dim_y,fuse", [(1600, 10), (3200, 16)])
 def test_virtual_slabs_auto_fuse_depths_at_bench_width(sfl, oracle, dim_y, fuse):
-    """8192-wide slabs big enough for the deeper auto fuse depths (10 from 6 M cells per slab, 16
+    """8192-wide slabs big enough for the deeper auto fuse depths (10 from 3 M cells per slab, 16
     from 12 M): two virtual ranks, everything on auto, against the oracle."""
     dim_x, iters, nranks = 8192, 20, 2
     rng = np.random.default_rng(dim_y)
