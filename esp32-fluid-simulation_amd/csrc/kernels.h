@@ -25,13 +25,19 @@ struct Slab {
 // Output rows [g_begin, g_end).  `p` may be read on global rows [valid_begin, valid_end)
 // only; a back-trace that needs another row raises *halo_flag (device int, may be null on a
 // whole-domain context where every row is present).
+// `src` (may be null = g): geometry of the array p when it is not the slab's own local array -- the
+// whole domain gathered on this GPU, used when the back-traces outrun the slab's ghost rows.
 hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
                                Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
-                               float dt, bool no_slip, int *halo_flag);
+                               float dt, bool no_slip, int *halo_flag, const Slab *src = nullptr);
 hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                   const float *vel, Slab g, int g_begin, int g_end,
                                   int valid_begin, int valid_end, float dt, bool no_slip,
-                                  int *halo_flag);
+                                  int *halo_flag, const Slab *src = nullptr);
+// reach[0] / reach[1] (device ints, atomicMax'ed: zero them first) = halo rows the back-traces of
+// rows [g_begin, g_end) need below / above that range.
+hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, Slab g, int g_begin,
+                                  int g_end, float dt);
 
 // subtract_gradient (finitediff.cpp:41-82) fused into the dye advection: every cell first projects
 // its OWN velocity (in place), then back-traces with it -- ino:276 + ino:282 in one pass over v.

@@ -125,6 +125,12 @@ struct sfl_context {
     // scratch field of sfl_host_advect_vec2f when the advected field is not the velocity
     float *host_scratch = nullptr;
 
+    // automatic advection halo (SFL_OPT_ADVECT_HALO = 0): device scratch of the back-trace reach
+    // {below, above}, and the whole advected field gathered on this GPU when the reach outruns the
+    // ghost rows (allocated on first need; sized for the 12-byte dye element)
+    int *d_reach = nullptr;
+    void *gather_buf = nullptr;
+
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1;
 
@@ -796,7 +802,7 @@ int sfl_destroy(sfl_context *c)
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
                     (void *)c->sor_block, (void *)c->halo_flag,
                     (void *)c->d_force_cells, (void *)c->d_force_vel, (void *)c->d_image,
-                    (void *)c->host_scratch})
+                    (void *)c->host_scratch, (void *)c->d_reach, c->gather_buf})
         if (m) (void)hipFree(m);
     for (auto &st : c->force_stage) {
         if (st.cells) (void)hipHostFree(st.cells);
@@ -829,8 +835,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_sor_fuse = value;
             return SFL_OK;
         case SFL_OPT_ADVECT_HALO:
-            if (value < 1 || value > kGhostRows)
-                return fail(SFL_ERR_INVALID, "advect halo must be 1..%d rows", kGhostRows);
+            if (value < 0 || value > kGhostRows)
+                return fail(SFL_ERR_INVALID, "advect halo must be 0 (auto) or 1..%d rows", kGhostRows);
             c->opt_advect_halo = value;
             return SFL_OK;
         case SFL_OPT_SOR_ROWS:
@@ -1002,6 +1008,117 @@ int sfl_field_device_ptr(sfl_context *c, int field, void **dev_ptr)
     return SFL_OK;
 }
 
+
+// ---- slab advection: which rows of the advected field does a slab need? --------------------------
+// A back-trace reads the field up to |v_y| dt + 1 rows away from its cell (advect.h:81, :38-42).
+// With a fixed halo (SFL_OPT_ADVECT_HALO = h >= 1) h rows are exchanged and a back-trace that leaves
+// them raises SFL_ERR_HALO at the next sfl_synchronize.  With SFL_OPT_ADVECT_HALO = 0 the reach is
+// MEASURED first (backtrace_reach_kernel over the owned cells, maximum over all slabs: every rank
+// must exchange the same number of rows) and then
+//   * reach <= ghost rows and <= the thinnest slab: exactly that many rows are exchanged;
+//   * otherwise the whole field is gathered on every GPU (SURVEY 8e's all-gather fallback) and the
+//     kernel samples the gathered copy -- correct for any velocity, at the price of the copy.
+// The measurement costs a small kernel, a 2-int all-reduce and one host round trip per advection.
+struct AdvectPlan {
+    int halo = 0;         // rows to exchange per side (fixed or measured)
+    bool gather = false;  // sample a gathered copy of the whole field instead
+    bool flag = true;     // fixed halo: let the kernel report a back-trace that leaves it
+};
+
+int measure_reach(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int *reach_out)
+{
+    int reach = 0;
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        if (!c->d_reach) {
+            void *m = nullptr;
+            HIP_TRY(hipMalloc(&m, 2 * sizeof(int)));
+            c->d_reach = static_cast<int *>(m);
+        }
+        HIP_TRY(hipMemsetAsync(c->d_reach, 0, 2 * sizeof(int), c->stream));
+        HIP_TRY(sfl::launch_backtrace_reach(c->stream, c->d_reach, c->vel, c->geom, c->g0, c->g1, dt));
+    }
+    if (ctx->comm) {  // maximum over the ranks, on the exchange stream like every RCCL operation
+        Overlap o;
+        SFL_TRY(overlap_of(ctx, &o));
+        HIP_TRY(hipEventRecord(o.ready, o.compute));
+        HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
+        NCCL_TRY(ncclAllReduce(ctx->d_reach, ctx->d_reach, 2, ncclInt32, ncclMax, ctx->comm, o.xstream));
+        HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+        HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
+    }
+    for (sfl_context *c : peers) {
+        int r[2] = {0, 0};
+        SFL_TRY(use_device(c));
+        HIP_TRY(hipMemcpyAsync(r, c->d_reach, sizeof r, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        reach = std::max(reach, std::max(r[0], r[1]));
+    }
+    *reach_out = reach;
+    return SFL_OK;
+}
+
+int plan_advect(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, AdvectPlan *plan)
+{
+    *plan = AdvectPlan{};
+    if (ctx->nranks == 1) return SFL_OK;
+    if (ctx->opt_advect_halo > 0) {
+        plan->halo = ctx->opt_advect_halo;
+        return SFL_OK;
+    }
+    int reach = 0;
+    SFL_TRY(measure_reach(ctx, peers, dt, &reach));
+    plan->flag = false;
+    if (reach <= kGhostRows && reach <= min_owned_rows(ctx))
+        plan->halo = reach;
+    else
+        plan->gather = true;
+    return SFL_OK;
+}
+
+// Gather the whole `field` (owned rows of every slab) into each context's gather_buf.
+int gather_field(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field)
+{
+    const size_t eb = field_elem_bytes(field);
+    const size_t row_bytes = (size_t)ctx->dim_x * eb;
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        if (!c->gather_buf) HIP_TRY(hipMalloc(&c->gather_buf, (size_t)c->gdim_y * c->dim_x * 12));
+        ++c->last_exchanges;
+    }
+    auto owned = [&](sfl_context *c) {
+        return static_cast<char *>(field_ptr(c, field)) + c->owned_offset_cells() * eb;
+    };
+    if (ctx->group) {
+        for (sfl_context *c : peers)
+            for (sfl_context *m : peers)
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(c->gather_buf) + (size_t)m->g0 * row_bytes, owned(m),
+                                       (size_t)(m->g1 - m->g0) * row_bytes, hipMemcpyDeviceToDevice, c->stream));
+        return SFL_OK;
+    }
+    sfl_context *c = ctx;
+    if (!c->comm) return fail(SFL_ERR_STATE, "slab %d/%d has no communicator", c->rank, c->nranks);
+    Overlap o;
+    SFL_TRY(overlap_of(c, &o));
+    HIP_TRY(hipEventRecord(o.ready, o.compute));
+    HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(c->gather_buf) + (size_t)c->g0 * row_bytes, owned(c),
+                           (size_t)(c->g1 - c->g0) * row_bytes, hipMemcpyDeviceToDevice, o.xstream));
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) continue;
+        int b = 0, e = 0;
+        sfl::slab_rows(c->gdim_y, c->nranks, r, &b, &e);
+        NCCL_TRY(ncclSend(owned(c), (size_t)(c->g1 - c->g0) * row_bytes, ncclChar, r, c->comm, o.xstream));
+        NCCL_TRY(ncclRecv(static_cast<char *>(c->gather_buf) + (size_t)b * row_bytes, (size_t)(e - b) * row_bytes,
+                          ncclChar, r, c->comm, o.xstream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+    HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
+    return SFL_OK;
+}
+
 // ---- operators ---------------------------------------------------------------------------
 int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
 {
@@ -1011,13 +1128,23 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure(c, c->vel_tmp, 8, false));
     }
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, ctx->opt_advect_halo));
+    AdvectPlan plan;
+    SFL_TRY(plan_advect(ctx, peers, dt, &plan));
+    if (plan.gather)
+        SFL_TRY(gather_field(ctx, peers, SFL_FIELD_VELOCITY));
+    else
+        SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, plan.halo));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
-        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
-        HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
-                                         clip_lo(c, c->g0 - h), clip_hi(c, c->g1 + h), dt,
-                                         no_slip != 0, c->nranks > 1 ? c->halo_flag : nullptr));
+        const sfl::Slab whole{c->dim_x, c->gdim_y, 0, c->gdim_y};
+        if (plan.gather)
+            HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, static_cast<const float *>(c->gather_buf),
+                                             c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
+                                             nullptr, &whole));
+        else
+            HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
+                                             clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
+                                             no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr));
         std::swap(c->vel, c->vel_tmp);  // ino:255
     }
     return SFL_OK;
@@ -1032,13 +1159,23 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
         SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    AdvectPlan plan;
+    SFL_TRY(plan_advect(ctx, peers, dt, &plan));
+    if (plan.gather)
+        SFL_TRY(gather_field(ctx, peers, SFL_FIELD_COLOR));
+    else
+        SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, plan.halo));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
-        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
-        HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, c->col, c->vel, c->geom, c->g0,
-                                            c->g1, clip_lo(c, c->g0 - h), clip_hi(c, c->g1 + h), dt,
-                                            no_slip != 0, c->nranks > 1 ? c->halo_flag : nullptr));
+        const sfl::Slab whole{c->dim_x, c->gdim_y, 0, c->gdim_y};
+        if (plan.gather)
+            HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, static_cast<const uint32_t *>(c->gather_buf),
+                                                c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
+                                                nullptr, &whole));
+        else
+            HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, c->col, c->vel, c->geom, c->g0, c->g1,
+                                                clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
+                                                no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr));
         std::swap(c->col, c->col_tmp);  // ino:286
     }
     return SFL_OK;
@@ -1183,7 +1320,8 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
     for (sfl_context *c : peers_of(ctx)) SFL_TRY(apply_queued_forces(c));  // ino:264-269
     SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
     SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));     // ino:275
-    if (ctx->opt_fuse_projection) {
+    // (slabs with the automatic advection halo measure the reach of the PROJECTED velocity first: two kernels)
+    if (ctx->opt_fuse_projection && !(ctx->nranks > 1 && ctx->opt_advect_halo == 0)) {
         SFL_TRY(project_and_advect_color(ctx, dt, dx));    // ino:276 + ino:281-287, one pass over v
     } else {
         SFL_TRY(sfl_subtract_gradient(ctx, dx));           // ino:276

@@ -88,9 +88,10 @@ __device__ __forceinline__ bool rows_available(const SrcPos &s, int valid_begin,
 // ---- advect<Vector2<float>, float>  (advect.h:24-85) ---------------------------------
 template <bool NO_SLIP>
 __global__ void __launch_bounds__(kBlock)
-advect_vec2f_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *vel, Slab g,
+advect_vec2f_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *vel, Slab g, Slab gs,
                     int g_begin, int g_end, int valid_begin, int valid_end, float dt, int *halo_flag)
-{
+{   // g: geometry of next_p and vel (the slab); gs: geometry of the advected field p (the slab's own
+    // array, or the gathered whole domain when the back-trace outruns the ghost rows)
     const int i = blockIdx.x * kAdvTileX + threadIdx.x;
     const int gj = g_begin + blockIdx.y * kAdvTileY + threadIdx.y;
     if (gj >= g_end) return;
@@ -104,7 +105,7 @@ advect_vec2f_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *
         if (halo_flag) atomicOr(halo_flag, 1);
         return;
     }
-    const size_t t = lcell(g, s.ci, s.cj);
+    const size_t t = lcell(gs, s.ci, s.cj);
     float2 r;
     if (!s.x_oob && !s.y_oob) {
         const float2 p11 = p[t], p12 = p[t + g.dim_x], p21 = p[t + 1], p22 = p[t + g.dim_x + 1];
@@ -153,7 +154,7 @@ __device__ __forceinline__ uint32_t uq_mix(float t, uint32_t a, uint32_t b)
 // the separate pass over v of ino:276 followed by ino:282 (same arithmetic, same results).
 template <bool NO_SLIP, bool FUSE_GRAD>
 __global__ void __launch_bounds__(kBlock)
-advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 *vel, Slab g,
+advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 *vel, Slab g, Slab gs,
                        int g_begin, int g_end, int valid_begin, int valid_end, float dt, int *halo_flag,
                        const float *__restrict__ pressure, float two_dx_inv)
 {
@@ -183,7 +184,7 @@ advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 
         if (halo_flag) atomicOr(halo_flag, 1);
         return;
     }
-    const size_t t = lcell(g, s.ci, s.cj);
+    const size_t t = lcell(gs, s.ci, s.cj);
     uq3 r;
     if (!s.x_oob && !s.y_oob) {
         const uq3 p11 = load_uq3(p, t), p12 = load_uq3(p, t + g.dim_x);
@@ -216,6 +217,32 @@ advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 
     o[0] = r.x;
     o[1] = r.y;
     o[2] = r.z;
+}
+
+// ---- how far do the back-traces of a slab reach beyond its owned rows? ------------------------
+// reach[0] = max over owned cells of (g_begin - first source row), reach[1] = max of (last source
+// row - (g_end - 1)), both >= 0: the halo rows an advection of this slab needs below / above
+// (exactly the rows rows_available() will ask for).  One atomicMax per wave.
+__global__ void __launch_bounds__(kBlock)
+backtrace_reach_kernel(int *reach, const float2 *__restrict__ vel, Slab g, int g_begin, int g_end, float dt)
+{
+    const int i = blockIdx.x * kAdvTileX + threadIdx.x;
+    const int gj = g_begin + blockIdx.y * kAdvTileY + threadIdx.y;
+    int below = 0, above = 0;
+    if (gj < g_end && i < g.dim_x) {
+        const float2 u = vel[lcell(g, i, gj)];
+        const SrcPos s = classify((float)i - u.x * dt, (float)gj - u.y * dt, g.dim_x, g.gdim_y);
+        below = max(g_begin - s.cj, 0);
+        above = max(s.cj + (s.y_oob ? 0 : 1) - (g_end - 1), 0);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        below = max(below, __shfl_xor(below, off));
+        above = max(above, __shfl_xor(above, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (below > 0) atomicMax(reach, below);
+        if (above > 0) atomicMax(reach + 1, above);
+    }
 }
 
 // ---- calculate_divergence (finitediff.cpp:9-39) -------------------------------------------
@@ -408,20 +435,31 @@ inline dim3 grid_cells(int cells_per_row, int rows) { return dim3((cells_per_row
 
 }  // namespace
 
-hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
-                               Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
-                               float dt, bool no_slip, int *halo_flag)
+hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, Slab g, int g_begin, int g_end,
+                                  float dt)
 {
     if (g_end <= g_begin) return hipSuccess;
+    SFL_ADV_GRID(g.dim_x, g_end - g_begin);
+    backtrace_reach_kernel<<<agrid, ablock, 0, s>>>(reach, reinterpret_cast<const float2 *>(vel), g, g_begin,
+                                                    g_end, dt);
+    return hipGetLastError();
+}
+
+hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
+                               Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
+                               float dt, bool no_slip, int *halo_flag, const Slab *src)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const Slab gs = src ? *src : g;
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *o = reinterpret_cast<float2 *>(next_p);
     auto *pi = reinterpret_cast<const float2 *>(p);
     auto *vi = reinterpret_cast<const float2 *>(vel);
     if (no_slip)
-        advect_vec2f_kernel<true><<<agrid, ablock, 0, s>>>(o, pi, vi, g, g_begin, g_end, valid_begin,
+        advect_vec2f_kernel<true><<<agrid, ablock, 0, s>>>(o, pi, vi, g, gs, g_begin, g_end, valid_begin,
                                                           valid_end, dt, halo_flag);
     else
-        advect_vec2f_kernel<false><<<agrid, ablock, 0, s>>>(o, pi, vi, g, g_begin, g_end, valid_begin,
+        advect_vec2f_kernel<false><<<agrid, ablock, 0, s>>>(o, pi, vi, g, gs, g_begin, g_end, valid_begin,
                                                            valid_end, dt, halo_flag);
     return hipGetLastError();
 }
@@ -429,17 +467,18 @@ hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, con
 hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                   const float *vel, Slab g, int g_begin, int g_end,
                                   int valid_begin, int valid_end, float dt, bool no_slip,
-                                  int *halo_flag)
+                                  int *halo_flag, const Slab *src)
 {
     if (g_end <= g_begin) return hipSuccess;
+    const Slab gs = src ? *src : g;
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *vi = reinterpret_cast<float2 *>(const_cast<float *>(vel));  // read-only without FUSE_GRAD
     if (no_slip)
         advect_vec3uq32_kernel<true, false><<<agrid, ablock, 0, s>>>(
-            next_p, p, vi, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
+            next_p, p, vi, g, gs, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
     else
         advect_vec3uq32_kernel<false, false><<<agrid, ablock, 0, s>>>(
-            next_p, p, vi, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
+            next_p, p, vi, g, gs, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, nullptr, 0.0f);
     return hipGetLastError();
 }
 
@@ -453,10 +492,10 @@ hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const
     auto *vi = reinterpret_cast<float2 *>(vel);
     if (no_slip)
         advect_vec3uq32_kernel<true, true><<<agrid, ablock, 0, s>>>(
-            next_p, p, vi, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
+            next_p, p, vi, g, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
     else
         advect_vec3uq32_kernel<false, true><<<agrid, ablock, 0, s>>>(
-            next_p, p, vi, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
+            next_p, p, vi, g, g, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
     return hipGetLastError();
 }
 

@@ -313,7 +313,7 @@ def test_api_error_paths(sfl):
     cap = sfl.capi
     with sfl.Solver(32, 16) as s:
         for opt, bad in ((cap.OPT_SOR_KERNEL, 3), (cap.OPT_SOR_FUSE, 7), (cap.OPT_SOR_FUSE, 18),
-                         (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_SOR_LANE_CELLS, 4), (cap.OPT_ADVECT_HALO, 0), (cap.OPT_SOR_HALO, 1),
+                         (cap.OPT_SOR_LANE_CELLS, 3), (cap.OPT_SOR_LANE_CELLS, 4), (cap.OPT_ADVECT_HALO, -1), (cap.OPT_ADVECT_HALO, 65), (cap.OPT_SOR_HALO, 1),
                          (99, 0)):
             with pytest.raises(sfl.SflError) as e:
                 s.set_option(opt, bad)
@@ -684,3 +684,55 @@ def test_baseline_config5_slab_program_vs_oracle(sfl, oracle):
             s.close()
     assert info["fuse"] == 16 and info["launches"] == 25 and info["exchanges"] == 7
     assert_bit_equal(got, want, "C5 slab program: 16384 x 4096 in two slabs, 200 iterations")
+
+
+@pytest.mark.parametrize("nranks,dim_y,vy,expect", [(2, 200, 9.0, "halo"), (3, 300, 40.5, "halo"), (4, 400, 130.0, "gather"),
+                                                    (8, 96, 20.0, "gather"), (2, 64, -700.0, "gather")])
+def test_automatic_advection_halo_and_gather_fallback(sfl, oracle, nranks, dim_y, vy, expect):
+    """SFL_OPT_ADVECT_HALO = 0: the reach of the back-traces is measured before every advection; it is
+    exchanged exactly when it fits the ghost rows and the thinnest slab, otherwise the whole field is
+    gathered on every (virtual) GPU (all-gather fallback).  Vertical speeds of `vy` rows per
+    step, far beyond the default 4-row halo: velocity self-advection, dye advection and a whole step
+    against the oracle; never an SFL_ERR_HALO."""
+    dim_x, iters = 96, 5
+    rng = np.random.default_rng(int(abs(vy)) + nranks)
+    v = np.empty((dim_y, dim_x, 2), np.float32)
+    v[..., 0] = rng.uniform(-60, 60, (dim_y, dim_x))
+    v[..., 1] = (vy * 30.0) * rng.uniform(0.2, 1.0, (dim_y, dim_x))     # rows per step = v_y * dt
+    c = rng.integers(0, 2 ** 31, (dim_y, dim_x, 3), dtype=np.uint32)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, 0)
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+
+        def load():
+            for s in slabs:
+                s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+                s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        load()
+        slabs[0].advect_color(DT, False)
+        slabs[0].synchronize()
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), oracle.advect_vec3uq32(c, v, DT, False), "dye advection")
+        slabs[0].advect_velocity(DT, True)
+        slabs[0].synchronize()
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), oracle.advect_vec2f(v, v, DT, True), "velocity advection")
+        load()
+        slabs[0].step(DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        want = oracle.step(v, c, DT, 1.0, iters, OMEGA)
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), want[0], "step: velocity")
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), want[3], "step: colour")
+        # the same fields with the default fixed halo must be REPORTED, not silently wrong
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, 4)
+        load()
+        slabs[0].advect_velocity(DT, True)
+        with pytest.raises(sfl.SflError) as e:
+            slabs[0].synchronize()
+        assert e.value.code == sfl.capi.ERR_HALO
+    finally:
+        for s in slabs:
+            s.close()
+    reach = abs(vy) + 1
+    thinnest = dim_y // nranks
+    assert (expect == "gather") == (reach > 64 or reach > thinnest)
