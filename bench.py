@@ -22,7 +22,8 @@ the C++ library.
 Output: ONE JSON line on rank 0 (contract in the task statement), including
   parity        the pressure field left by the LAST TIMED solve, downloaded and compared bit for
                 bit with the reference CPU loop run on the very same right-hand side (downloaded
-                from the GPU); the process exits non-zero on a mismatch
+                from the GPU); plus one whole sim step at the two small BASELINE configs (61 x 81 and
+                2048^2), all four fields; the process exits non-zero on a mismatch
   roofline      the bound that binds the temporally blocked kernel (the pass over HBM: bytes really
                 moved, from the committed PMC passes, / launch duration by HIP events), the VALU
                 fraction beside it, and the SURVEY 8d algorithmic-bytes figure (labelled as a ratio)
@@ -111,8 +112,10 @@ def cpu_reference_solve(d, iters, min_seconds=8.0):
                             f"-ffp-contract=off); the first of them is the parity expectation"}
 
 
-def cpu_operator_times(dim_x, dim_y, iters):
-    """Per-operator wall time of the reference CPU path for ONE sim step (1 thread), ms."""
+def cpu_operator_times(dim_x, dim_y, iters, sfl=None):
+    """Per-operator wall time of the reference CPU path for ONE sim step (1 thread), ms -- and, with
+    `sfl` given, the same step on the GPU compared bit for bit with what the reference produced
+    (parity gate on the small BASELINE configs in the same run)."""
     path = cpu_path()
     v = synthetic_velocity(dim_x, 0, dim_y)
     c = synthetic_color(dim_x, 0, dim_y)
@@ -128,9 +131,20 @@ def cpu_operator_times(dim_x, dim_y, iters):
     d = timed("calculate_divergence", lambda: path.divergence(va, 1.0))
     p = timed("poisson_solve", lambda: path.poisson_solve(d, 1.0, iters, om))
     vp = timed("subtract_gradient", lambda: path.subtract_gradient(va, p, 1.0))
-    timed("advect_color", lambda: path.advect_vec3uq32(c, vp, dt, False))
+    cp = timed("advect_color", lambda: path.advect_vec3uq32(c, vp, dt, False))
     out["step"] = sum(out.values())
-    return {"grid": [dim_x, dim_y], "iters": iters, "kind": path.kind, "ms": out}
+    rec = {"grid": [dim_x, dim_y], "iters": iters, "kind": path.kind, "ms": out}
+    if sfl is not None:
+        with sfl.Solver(dim_x, dim_y) as g:
+            g.upload(sfl.capi.FIELD_VELOCITY, v)
+            g.upload(sfl.capi.FIELD_COLOR, c)
+            g.step(dt, 1.0, iters, om)
+            g.synchronize()
+            same = all(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+                       for a, b in ((g.download(sfl.capi.FIELD_VELOCITY), vp), (g.download(sfl.capi.FIELD_DIVERGENCE), d),
+                                    (g.download(sfl.capi.FIELD_PRESSURE), p), (g.download(sfl.capi.FIELD_COLOR), cp)))
+        rec["gpu_step_bit_exact"] = bool(same)
+    return rec
 
 
 def gpu_operator_times(s, iters, cells, reps=3):
@@ -518,8 +532,14 @@ def run_rank(args):
             out["cpu_baseline"]["host_cpu"] = host_cpu_model()
             # the other half of SURVEY 8(d): the reference's per-operator times for one sim step,
             # in full at the two small BASELINE configs (C1 as 61 x 81, C2)
-            out["cpu_baseline"]["sim_step_per_operator"] = [cpu_operator_times(61, 81, 20),
-                                                            cpu_operator_times(2048, 2048, 40)]
+            small = [cpu_operator_times(61, 81, 20, sfl), cpu_operator_times(2048, 2048, 40, sfl)]
+            out["cpu_baseline"]["sim_step_per_operator"] = small
+            # parity gate on the small BASELINE configs: the whole sim step, all four fields
+            out["parity"]["small_configs"] = [{"grid": r["grid"], "iters": r["iters"], "what": "one whole sim step, "
+                                               "velocity / divergence / pressure / dye vs the reference CPU path",
+                                               "bit_exact": r["gpu_step_bit_exact"]} for r in small]
+            if not all(r["gpu_step_bit_exact"] for r in small):
+                out["parity"]["bit_exact"] = False
         print(json.dumps(out), flush=True)
         if parity and not parity["bit_exact"]:
             print(f"bench.py: PARITY FAILURE: {parity['mismatching_cells']} cells differ from the "
