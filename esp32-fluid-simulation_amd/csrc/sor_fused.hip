@@ -17,6 +17,12 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr size_t kNtStoreCells = 24u << 20;  // local cells from which p is stored non-temporally
+constexpr int kFlipTiles = 1;                // alternate the stream direction of vertically adjacent tiles
+inline int flip_tiles()
+{
+    static const int on = [] { const char *e = getenv("SFL_SOR_FLIP"); return e ? atoi(e) : kFlipTiles; }();
+    return on;
+}
 constexpr int kThreads = 64 * kWavesPerBlock;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -48,17 +54,20 @@ struct WaveCommon {
     int dim_x, gdim_y;
     int grow0;           // global row of local row 0
     int row_lo, row_hi;  // global rows present in the local arrays AND inside the domain
+    int row_sign;        // +1: pipeline row index = domain row; -1: its negative (tile streamed top-down)
 
-    __device__ __forceinline__ sor::RowFacts row_facts(int r) const
+    // the pipeline speaks in row INDICES t; domain row = row_sign * t (same parity either way)
+    __device__ __forceinline__ sor::RowFacts row_facts(int t) const
     {
+        const int r = row_sign * t;
         return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
     }
     template <class P>
     __device__ __forceinline__ void poison(P &) const {}
-    __device__ __forceinline__ int row_bytes(int r) const { return (r - grow0) * dim_x * 4; }
-    __device__ __forceinline__ int load_row_bytes(int r) const
+    __device__ __forceinline__ int row_bytes(int t) const { return (row_sign * t - grow0) * dim_x * 4; }
+    __device__ __forceinline__ int load_row_bytes(int t) const
     {
-        return row_bytes(min(max(r, row_lo), row_hi - 1));
+        return (min(max(row_sign * t, row_lo), row_hi - 1) - grow0) * dim_x * 4;
     }
 };
 
@@ -222,6 +231,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.grow0 = g.grow0;
         bk.row_lo = max(g.grow0, 0);
         bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
+        bk.row_sign = 1;
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
         return bk;
     };
@@ -231,6 +241,12 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
+    } else if (sor::tile_may_flip(t, rect)) {  // streamed top-down: pipeline index = -row
+        B bk = backend();
+        bk.row_sign = -1;
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        const sor::EdgeCell<B> none{};
+        sor::stream_tile<B, NS, false, DX1, ZERO_IN, true>(bk, c, none, none, 1 - r1, 1 - r0);
     } else {
         B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
@@ -289,7 +305,7 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
     for (int chunks = 1; chunks <= max_chunks; ++chunks) {
         const int rpc = (rows + chunks - 1) / chunks;
         const sor::Tiling t = sor::make_tiling(ns, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin,
-                                               g_end, rpc, sor::kEdgeRowCost16);
+                                               g_end, rpc, sor::kEdgeRowCost16, kFlipTiles);
         const long tiles = t.n_tiles;
         const double per_simd = (double)tiles / simds;
         const long serial = (tiles + simds - 1) / simds;          // tiles one SIMD works through
@@ -319,7 +335,7 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
         if (rpc <= 0)
             rpc = auto_rows_per_chunk<B>(g, g_begin, g_end, NS, resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
         return sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin, g_end, rpc,
-                                sor::kEdgeRowCost16);
+                                sor::kEdgeRowCost16, flip_tiles());
     };
     const sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
     const int tiles = t1.n_tiles + t2.n_tiles;

@@ -143,7 +143,10 @@ constexpr bool steady_rows_are_output(int ns) { return prologue_trips(ns) * ring
 
 // The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool GUARD_STORE, int U>
+// FLIP: the tile is streamed TOP-DOWN (the backend maps pipeline row index t to domain row -t, same
+// parity): the pipeline's "previous row" is then the N neighbour and its "next row" the S neighbour,
+// and the reference's sum ((W + E) + S) + N keeps its order by swapping the two operands here.
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool GUARD_STORE, bool FLIP, int U>
 SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                     const EdgeCell<B> &ecb, int y, int out_begin, int out_end)
 {
@@ -195,7 +198,8 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V e = ev ? oc : bk.from_upper_lane(oc);
             const V d = bk.ring_load(i0, 0);
             const RowFacts rf = bk.row_facts(r);
-            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[im], pp.O[ip], d, ev ? eca : ecb, rf);
+            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[FLIP ? ip : im], pp.O[FLIP ? im : ip], d,
+                                           ev ? eca : ecb, rf);
         }
         // ---- O_m of row y - 2m ----
         if (pass_runs(TRIP, RING, U, 2 * m)) {
@@ -210,7 +214,8 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V e = ev ? bk.from_upper_lane(oc) : oc;
             const V d = bk.ring_load(i0, 1);
             const RowFacts rf = bk.row_facts(r);
-            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[im], pp.E[ip], d, ev ? ecb : eca, rf);
+            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[FLIP ? ip : im], pp.E[FLIP ? im : ip], d,
+                                              ev ? ecb : eca, rf);
             if (m < NS / 2) {
                 pp.O[i0] = res;
             } else if (!GUARD_STORE || (r >= out_begin && r < out_end)) {  // finished row leaves
@@ -228,7 +233,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
 // loads in flight and drains them all -- s_waitcnt vmcnt(0) -- once per trip); only the last,
 // partial trip of a tile checks after every iteration whether the remaining rows still need to
 // enter.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool PARTIAL, int... Us>
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, int TRIP, bool PARTIAL, bool FLIP, int... Us>
 SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B> &eca,
                          const EdgeCell<B> &ecb, int y, int out_begin, int out_end,
                          std::integer_sequence<int, Us...>)
@@ -238,13 +243,14 @@ SFL_HD void run_unrolled(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeC
     constexpr bool guard = PARTIAL || TRIP < kSteadyTrip || !steady_rows_are_output(NS) ||
                            (EDGE && !edge_prologue(NS));
     (void)(((!PARTIAL || y + Us < y_stop) &&
-            (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, guard, Us>(bk, pp, c, eca, ecb, y + Us, out_begin,
-                                                                 out_end),
+            (iterate<B, NS, EDGE, DX1, ZERO_IN, TRIP, guard, FLIP, Us>(bk, pp, c, eca, ecb, y + Us, out_begin,
+                                                                       out_end),
              true)) && ...);
 }
 
-// Stream one tile: output rows [out_begin, out_end), all NS passes.
-template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN>
+// Stream one tile: output rows [out_begin, out_end) IN PIPELINE ROW INDICES (= domain rows, or their
+// negatives when FLIP), all NS passes.
+template <class B, int NS, bool EDGE, bool DX1, bool ZERO_IN, bool FLIP = false>
 SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
                         const EdgeCell<B> &ecb, int out_begin, int out_end)
 {
@@ -266,19 +272,19 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
 
     constexpr auto us = std::make_integer_sequence<int, RING>{};
     if ((!EDGE || edge_prologue(NS)) && y + RING <= y_stop) {  // prologue trips: passes join one by one
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 0, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 0, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
         y += RING;
         if (prologue_trips(NS) >= 2 && y + RING <= y_stop) {
-            run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
+            run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
             y += RING;
         }
     }
     static_assert(prologue_trips(NS) <= kSteadyTrip, "prologue trips");
     for (; y + RING <= y_stop; y += RING)
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, false>(bk, pp, c, eca, ecb, y, out_begin,
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin,
                                                                     out_end, us);
     if (y < y_stop)
-        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, true>(bk, pp, c, eca, ecb, y, out_begin,
+        run_unrolled<B, NS, EDGE, DX1, ZERO_IN, kSteadyTrip, true, FLIP>(bk, pp, c, eca, ecb, y, out_begin,
                                                                    out_end, us);
 }
 
@@ -310,11 +316,13 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
+    int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect)
 };
 
 struct TileRect {
     int strip;
     int r0, r1;  // output rows [r0, r1)
+    int flip;    // streamed top-down (interior tiles only)
 };
 
 SFL_HD int strip_step(const Tiling &t) { return t.tile_cols - 2 * t.halo_cols; }
@@ -341,9 +349,10 @@ SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 
 // `balance16` = 0: every tile gets rows_per_chunk rows; otherwise pass kEdgeRowCost16.
 SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin,
-                          int g_end, int rows_per_chunk, int balance16)
+                          int g_end, int rows_per_chunk, int balance16, int flip = 0)
 {
     Tiling t;
+    t.flip = flip;
     const int rows = g_end - g_begin;
     t.ns = ns;
     t.dim_x = dim_x;
@@ -386,12 +395,20 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
 
 // Tile index -> strip and output rows.  Inner strips come first, chunk-major (the waves of a
 // block are neighbouring strips of one chunk), then the boundary strips.
+// Alternating stream direction (t.flip): the even chunks of an inner strip are streamed bottom-up,
+// the odd ones top-down.  Vertically adjacent tiles re-read 2 NS rows of each other; all tiles of a
+// launch start together and take the same time, so with one direction a tile reads the shared rows
+// at the END of its life and its upper neighbour at the BEGINNING of its own -- a tile's life apart,
+// long evicted from L2.  With alternating directions both sharers reach a shared band at the same
+// moment (both at the start, or both at the end): the second read hits the XCD's L2.
 SFL_HD TileRect tile_rect(const Tiling &t, int tile)
 {
     TileRect r;
+    r.flip = 0;
     const int inner_tiles = t.n_inner * t.n_chunks;
     if (tile < inner_tiles) {
         const int chunk = tile / t.n_inner;
+        r.flip = t.flip && (chunk & 1);
         r.strip = 1 + (tile - chunk * t.n_inner);
         const int has_first = t.rows_first > 0;
         if (has_first && chunk == 0) {
@@ -414,6 +431,13 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile)
         r.r1 = r.r0 + t.rows_edge < t.g_end ? r.r0 + t.rows_edge : t.g_end;
     }
     return r;
+}
+
+// may the tile be streamed top-down?  (the RING rows of slack the pipeline needs beyond its last
+// output row then lie BELOW the tile)
+SFL_HD bool tile_may_flip(const Tiling &t, const TileRect &r)
+{
+    return r.flip && r.r0 - t.ns - ring_rows(t.ns) > 0;
 }
 
 // does the tile touch the domain boundary (=> EDGE path)?

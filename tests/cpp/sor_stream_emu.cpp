@@ -51,6 +51,7 @@ struct EmuBackend {
     int dim_x, gdim_y, grow0, row_lo, row_hi;
     int x0;       // column of lane 0's cell a
     int out_lo, out_hi;
+    int row_sign = 1;  // pipeline row index t -> domain row row_sign * t (-1: tile streamed top-down)
     bool vec2;    // emulate the 8-byte access variant (pair handled as a whole)
     bool poison_on;
     int tile_r0, tile_r1;  // output rows of the tile being streamed
@@ -90,8 +91,9 @@ struct EmuBackend {
         for (int i = 0; i < 63; ++i) r.l[i] = x.l[i + 1];
         return r;
     }
-    sfl::sor::RowFacts row_facts(int r) const
+    sfl::sor::RowFacts row_facts(int t) const
     {
+        const int r = row_sign * t;
         return {r >= 0 && r < gdim_y, r > 0 && r < gdim_y - 1};
     }
     template <class P>
@@ -106,8 +108,9 @@ struct EmuBackend {
     // Mirrors the GPU backend: loads are unconditional with clamped row / column.  To be
     // stricter than the hardware, whatever a CLAMPED access would return is replaced by NaN:
     // the pipeline must mask it (domain boundary) or keep it out of the exact interior.
-    void load_row(int r, V &pa, V &pb, V &da, V &db) const
+    void load_row(int t, V &pa, V &pb, V &da, V &db) const
     {
+        const int r = row_sign * t;
         const bool row_ok = r >= row_lo && r < row_hi;
         const float nan = std::numeric_limits<float>::quiet_NaN();
         for (int i = 0; i < 64; ++i) {
@@ -124,8 +127,9 @@ struct EmuBackend {
             }
         }
     }
-    void store_row(int r, const V &a, const V &b) const
+    void store_row(int t, const V &a, const V &b) const
     {
+        const int r = row_sign * t;
         if (r < tile_r0 || r >= tile_r1) {  // a store outside the tile's output rows is a bug
             ++*stray_stores;
             return;
@@ -171,11 +175,11 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge, bool balance)
+               bool vec2, bool poison, bool force_edge, bool balance, bool flip, int *flipped_tiles)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
-                                 balance ? kEdgeRowCost16 : 0);
+                                 balance ? kEdgeRowCost16 : 0, flip);
     int stray = 0;
     {
         for (int tile = 0; tile < t.n_tiles; ++tile) {
@@ -202,6 +206,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.stray_stores = &stray;
             Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
             const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
+            const bool flipped = !edge && tile_may_flip(t, rect);
             const bool dx1 = dx == 1.0f;
             const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
@@ -209,6 +214,13 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             if (edge) {
                 if (dx1) { if (zero_in) EMU_RUN(true, true, true); else EMU_RUN(true, true, false); }
                 else     { if (zero_in) EMU_RUN(true, false, true); else EMU_RUN(true, false, false); }
+            } else if (flipped) {  // streamed top-down: pipeline index = -row (what the product does)
+                bk.row_sign = -1;
+#define EMU_FLIP(DX1, ZERO) stream_tile<EmuBackend, NS, false, DX1, ZERO, true>(bk, c, eca, ecb, 1 - r1, 1 - r0)
+                if (dx1) { if (zero_in) EMU_FLIP(true, true); else EMU_FLIP(true, false); }
+                else     { if (zero_in) EMU_FLIP(false, true); else EMU_FLIP(false, false); }
+#undef EMU_FLIP
+                ++*flipped_tiles;
             } else {
                 if (dx1) { if (zero_in) EMU_RUN(false, true, true); else EMU_RUN(false, true, false); }
                 else     { if (zero_in) EMU_RUN(false, false, true); else EMU_RUN(false, false, false); }
@@ -228,13 +240,13 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
-                 bool vec2, bool poison, bool force_edge, bool balance
+                 bool vec2, bool poison, bool force_edge, bool balance, bool flip, int *flipped_tiles
 #define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
 #define EMU_DEFINE(N)                                                                             \
     int emu_run_ns##N(EMU_ARGS)                                                                   \
     {                                                                                             \
         return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                            rows_per_chunk, vec2, poison, force_edge, balance);                   \
+                            rows_per_chunk, vec2, poison, force_edge, balance, flip, flipped_tiles); \
     }
 EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
 EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
@@ -253,18 +265,22 @@ EMU_DEFINE(16)
 
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
-//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles)
+//        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
+//        bit4 = every second chunk of an inner strip is streamed top-down (the product's default)
+// returns the number of tiles streamed top-down (>= 0), or a negative error
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
               int lrows, int g_begin, int g_end, int ns, float dx, float omega,
               int rows_per_chunk, int flags)
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
+    const bool flip = flags & 16;
+    int flipped_tiles = 0;
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
         return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
-                             omega, rows_per_chunk, vec2, poison, force_edge, balance) ? -3 : 0;
+                             omega, rows_per_chunk, vec2, poison, force_edge, balance, flip, &flipped_tiles) ? -3 : flipped_tiles;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)
         EMU_CASE(16)

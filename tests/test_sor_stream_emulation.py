@@ -29,16 +29,17 @@ def emu():
     lib.emu_tiling_cover.restype = C.c_int
 
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
-            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False):
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, flip=True):
         lrows, dim_x = d.shape
         gdim_y = lrows if gdim_y is None else gdim_y
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (16 if flip else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
-        assert rc == 0
+        assert rc >= 0
+        run.flipped_tiles = rc
         return out
     run.lib = lib
     return run
@@ -53,6 +54,7 @@ def test_fused_passes_from_zero(emu, oracle, dim_x, dim_y, ns):
     d = np.random.default_rng(dim_x * 1000 + dim_y).standard_normal((dim_y, dim_x)).astype(np.float32)
     want = oracle.poisson_solve(d, 1.0, ns // 2, OMEGA)
     assert_bit_equal(emu(None, d, ns, rows=16), want, "auto edge")
+    assert_bit_equal(emu(None, d, ns, rows=16, flip=False), want, "every tile bottom-up")
     assert_bit_equal(emu(None, d, ns, rows=40, force_edge=True), want, "forced edge path")
     assert_bit_equal(emu(None, d, ns, rows=16, uniform=True), want, "uniform tiling")
     if dim_x % 2 == 0:
@@ -66,6 +68,8 @@ def test_fused_passes_continue(emu, oracle, dim_x, dim_y, ns):
     d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
     p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
     assert_bit_equal(emu(p0, d, ns, rows=24), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "continue")
+    assert_bit_equal(emu(p0, d, ns, rows=24, flip=False), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA),
+                     "continue, every tile bottom-up")
     assert_bit_equal(emu(p0, d, ns, rows=24, dx=0.5, omega=np.float32(1.4)),
                      oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "dx, omega")
 
@@ -130,3 +134,22 @@ def test_tilings_partition_the_row_range(emu):
                 assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
                 counts[balance] = n
             assert counts[10] >= counts[0]
+
+
+@pytest.mark.parametrize("ns", [2, 4, 8, 10, 12, 16])
+@pytest.mark.parametrize("dim_x,dim_y,rows", [(420, 400, 23), (258, 300, 16), (640, 250, 9), (130, 500, 40)])
+def test_alternating_stream_direction(emu, oracle, ns, dim_x, dim_y, rows):
+    """Every second chunk of an inner strip is streamed TOP-DOWN (pipeline row index = -row; the S / N
+    operands of a relaxation swap places so that ((W + E) + S) + N keeps its order): vertically adjacent
+    tiles then read their shared halo rows at the same moment.  Tall grids with many chunks, odd and even
+    tile heights: same bits as the oracle, and top-down tiles really occur."""
+    rng = np.random.default_rng(ns * 13 + dim_y)
+    d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    p0 = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    assert_bit_equal(emu(p0, d, ns, rows=rows), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "continue")
+    flipped = emu.flipped_tiles
+    assert_bit_equal(emu(None, d, ns, rows=rows), oracle.poisson_solve(d, 1.0, ns // 2, OMEGA), "from zero")
+    assert_bit_equal(emu(p0, d, ns, rows=rows, dx=0.5, omega=np.float32(1.4)),
+                     oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "dx and omega")
+    if dim_x > 300:
+        assert flipped > 0, "no tile was streamed top-down"
