@@ -217,6 +217,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the reference solve on rank 0")
     ap.add_argument("--no-priming", action="store_true",
                     help="skip the ~80 ms of untimed solves that bring the GPU to its sustained clocks")
+    ap.add_argument("--advect-kernel", type=int, default=0,
+                    help="advection kernels: 0 auto, 1 one thread per cell, 2 LDS-staged tiles (A/B)")
     ap.add_argument("--no-fuse-projection", action="store_true",
                     help="sim step: separate subtract_gradient and dye-advection kernels (A/B)")
     ap.add_argument("--dry-run", action="store_true",
@@ -304,7 +306,7 @@ def run_rank(args):
     s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
                      (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
-                     (capi.OPT_SOR_HALO, args.sor_halo)):
+                     (capi.OPT_SOR_HALO, args.sor_halo), (capi.OPT_ADVECT_KERNEL, args.advect_kernel)):
         if val:
             s.set_option(opt, val)
     if args.no_fuse_projection:

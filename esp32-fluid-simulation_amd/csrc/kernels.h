@@ -29,11 +29,12 @@ struct Slab {
 // whole domain gathered on this GPU, used when the back-traces outrun the slab's ghost rows.
 hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
                                Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
-                               float dt, bool no_slip, int *halo_flag, const Slab *src = nullptr);
+                               float dt, bool no_slip, int *halo_flag, const Slab *src = nullptr,
+                               int kernel = 0);
 hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                   const float *vel, Slab g, int g_begin, int g_end,
                                   int valid_begin, int valid_end, float dt, bool no_slip,
-                                  int *halo_flag, const Slab *src = nullptr);
+                                  int *halo_flag, const Slab *src = nullptr, int kernel = 0);
 // reach[0] / reach[1] (device ints, atomicMax'ed: zero them first) = halo rows the back-traces of
 // rows [g_begin, g_end) need below / above that range.
 hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, Slab g, int g_begin,
@@ -44,7 +45,25 @@ hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, S
 hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                           float *vel, const float *pressure, Slab g, int g_begin,
                                           int g_end, int valid_begin, int valid_end, float dt,
-                                          bool no_slip, int *halo_flag, float two_dx_inv);
+                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel = 0);
+
+// `kernel` of the three launchers above: 1 = one thread per cell with a 4-texel gather from memory
+// (stencil_kernels.hip), 2 = the source window of a 64 x 32 tile staged in LDS (advect_tiled.hip),
+// 0 = automatic (2 from kAdvectTiledMinCells output cells).  Same arithmetic, same bits.
+constexpr int kAdvectTiledMinCells = 16384;
+hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *p, const float *vel, Slab g,
+                                     int g_begin, int g_end, int valid_begin, int valid_end, float dt,
+                                     bool no_slip, int *halo_flag, const Slab *src);
+// pressure != nullptr: the projection fused in (then src must be null)
+hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const uint32_t *p, float *vel,
+                                        const float *pressure, Slab g, int g_begin, int g_end, int valid_begin,
+                                        int valid_end, float dt, bool no_slip, int *halo_flag,
+                                        float two_dx_inv, const Slab *src);
+// advect(v_next, v, v) (ino:252-256) and calculate_divergence(div, v_next) (ino:274) in one pass of a
+// WHOLE-DOMAIN context (grow0 = 0, lrows = gdim_y): the advected tile and the ring around it are
+// differenced in LDS.  Same arithmetic as the two operators, same bits.
+hipError_t launch_advect_divergence_tiled(hipStream_t s, float *next_v, float *div, const float *v, Slab g,
+                                          float dt, bool no_slip, float two_dx_inv);
 
 // ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
 hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,

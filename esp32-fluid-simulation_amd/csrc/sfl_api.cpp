@@ -132,7 +132,8 @@ struct sfl_context {
     void *gather_buf = nullptr;
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
-        opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1;
+        opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
+        opt_advect_kernel = 0, opt_fuse_divergence = 1;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -619,6 +620,7 @@ struct HostCtx {
             c->opt_sor_fuse = fresh.opt_sor_fuse;
             c->opt_sor_rows = fresh.opt_sor_rows;
             c->opt_sor_lane_cells = fresh.opt_sor_lane_cells;
+            c->opt_advect_kernel = fresh.opt_advect_kernel;
             return SFL_OK;
         }
         if (k) {
@@ -851,6 +853,13 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_SOR_OVERLAP:
             c->opt_sor_overlap = value ? 1 : 0;
             return SFL_OK;
+        case SFL_OPT_FUSE_DIVERGENCE:
+            c->opt_fuse_divergence = value ? 1 : 0;
+            return SFL_OK;
+        case SFL_OPT_ADVECT_KERNEL:
+            if (value < 0 || value > 2) return fail(SFL_ERR_INVALID, "advection kernel must be 0, 1 or 2");
+            c->opt_advect_kernel = value;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -889,6 +898,8 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
         case SFL_OPT_SOR_OVERLAP: *value = c->opt_sor_overlap; return SFL_OK;
+        case SFL_OPT_ADVECT_KERNEL: *value = c->opt_advect_kernel; return SFL_OK;
+        case SFL_OPT_FUSE_DIVERGENCE: *value = c->opt_fuse_divergence; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -963,6 +974,8 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_sor_halo = z->opt_sor_halo;
         c->opt_fuse_projection = z->opt_fuse_projection;
         c->opt_sor_overlap = z->opt_sor_overlap;
+        c->opt_advect_kernel = z->opt_advect_kernel;
+        c->opt_fuse_divergence = z->opt_fuse_divergence;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
@@ -1140,11 +1153,12 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
         if (plan.gather)
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, static_cast<const float *>(c->gather_buf),
                                              c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
-                                             nullptr, &whole));
+                                             nullptr, &whole, c->opt_advect_kernel));
         else
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
                                              clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
-                                             no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr));
+                                             no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr,
+                                             nullptr, c->opt_advect_kernel));
         std::swap(c->vel, c->vel_tmp);  // ino:255
     }
     return SFL_OK;
@@ -1171,11 +1185,12 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
         if (plan.gather)
             HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, static_cast<const uint32_t *>(c->gather_buf),
                                                 c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
-                                                nullptr, &whole));
+                                                nullptr, &whole, c->opt_advect_kernel));
         else
             HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, c->col, c->vel, c->geom, c->g0, c->g1,
                                                 clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
-                                                no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr));
+                                                no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr,
+                                                nullptr, c->opt_advect_kernel));
         std::swap(c->col, c->col_tmp);  // ino:286
     }
     return SFL_OK;
@@ -1307,18 +1322,44 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
         const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
         HIP_TRY(sfl::launch_project_advect_vec3uq32(
             c->stream, c->col_tmp, c->col, c->vel, c->p, c->geom, c->g0, c->g1, clip_lo(c, c->g0 - h),
-            clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? c->halo_flag : nullptr, two_dx_inv));
+            clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? c->halo_flag : nullptr, two_dx_inv,
+            c->opt_advect_kernel));
         std::swap(c->col, c->col_tmp);  // ino:286
     }
+    return SFL_OK;
+}
+
+// ino:252-256 + ino:274 in one pass: possible when nothing happens between the two (no queued drag
+// forces, ino:264-269) and every neighbour of every cell is on this GPU (whole-domain context)
+static bool can_fuse_divergence(const sfl_context *c)
+{
+    if (!c->opt_fuse_divergence || c->nranks != 1 || c->group || !c->force_cells.empty()) return false;
+    const int64_t cells = (int64_t)c->dim_x * c->gdim_y;
+    return c->opt_advect_kernel == 2 || (c->opt_advect_kernel == 0 && cells >= sfl::kAdvectTiledMinCells);
+}
+
+static int advect_velocity_and_divergence(sfl_context *c, float dt, float dx)
+{
+    SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+    SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+    SFL_TRY(use_device(c));
+    const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36
+    HIP_TRY(sfl::launch_advect_divergence_tiled(c->stream, c->vel_tmp, c->div, c->vel, c->geom, dt, true, two_dx_inv));
+    std::swap(c->vel, c->vel_tmp);  // ino:255
     return SFL_OK;
 }
 
 int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
-    SFL_TRY(sfl_advect_velocity(ctx, dt, 1));              // ino:252-256
-    for (sfl_context *c : peers_of(ctx)) SFL_TRY(apply_queued_forces(c));  // ino:264-269
-    SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
+    if (can_fuse_divergence(ctx)) {
+        SFL_TRY(advect_velocity_and_divergence(ctx, dt, dx));  // ino:252-256 + ino:274
+    } else {
+        SFL_TRY(sfl_advect_velocity(ctx, dt, 1));              // ino:252-256
+        for (sfl_context *c : peers_of(ctx)) SFL_TRY(apply_queued_forces(c));  // ino:264-269
+        SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
+    }
     SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));     // ino:275
     // (slabs with the automatic advection halo measure the reach of the PROJECTED velocity first: two kernels)
     if (ctx->opt_fuse_projection && !(ctx->nranks > 1 && ctx->opt_advect_halo == 0)) {
@@ -1437,7 +1478,7 @@ int sfl_host_advect_vec2f(float *next_p, const float *p, const float *vel, int d
         src = c->host_scratch;
     }
     hipError_t e = sfl::launch_advect_vec2f(c->stream, c->vel_tmp, src, c->vel, c->geom, 0, dim_y, 0,
-                                            dim_y, dt, no_slip != 0, nullptr);
+                                            dim_y, dt, no_slip != 0, nullptr, nullptr, c->opt_advect_kernel);
     int rc = e == hipSuccess ? download_raw(c, c->vel_tmp, next_p, 8)
                              : fail(SFL_ERR_HIP, "advect launch failed: %s", hipGetErrorString(e));
     return t.done(rc);

@@ -9,81 +9,19 @@
 // Reference citations are file:line under /root/reference/ESP32-fluid-simulation/.
 #include <stdlib.h>
 
+#include "advect_math.h"
 #include "kernels.h"
 
 namespace sfl {
 namespace {
+
+using namespace advect_math;
 
 constexpr int kBlock = 256;
 // advection blocks are 64 x 4 cells (one wave per row segment, four rows per block): a sample reads
 // rows cj and cj + 1, so vertically adjacent waves share cache lines through the CU's L1 -- 20 %
 // faster on incoherent velocity fields, neutral on smooth ones (profiles/r01_advect_coherence_probe.txt)
 constexpr int kAdvTileX = 64, kAdvTileY = 4;
-
-__device__ __forceinline__ size_t lcell(const Slab &g, int i, int gj)
-{
-    return (size_t)(gj - g.grow0) * (size_t)g.dim_x + (size_t)i;
-}
-
-// lerp(t, a, b) = a*(1-t) + b*t  (advect.h:13-16)
-__device__ __forceinline__ float mix1(float t, float a, float b)
-{
-    const float wa = 1.0f - t;
-    const float pa = a * wa;
-    const float pb = b * t;
-    return pa + pb;
-}
-
-// uq32.h:13 / :15
-__device__ __forceinline__ uint32_t uq_narrow(float x) { return (uint32_t)(x + 0.5f); }
-__device__ __forceinline__ float uq_widen(uint32_t raw) { return (float)raw; }
-
-struct SrcPos {
-    bool x_under, y_under, x_oob, y_oob;
-    int ci, cj;
-    float di, dj;
-};
-
-// advect.h:26-35
-__device__ __forceinline__ SrcPos classify(float si, float sj, int dim_x, int gdim_y)
-{
-    SrcPos s;
-    const bool x_over = si >= (float)(dim_x - 1);
-    const bool y_over = sj >= (float)(gdim_y - 1);
-    const float fi = floorf(si), fj = floorf(sj);
-    s.x_under = si < 0.0f;
-    s.y_under = sj < 0.0f;
-    s.x_oob = s.x_under || x_over;
-    s.y_oob = s.y_under || y_over;
-    s.di = si - fi;
-    s.dj = sj - fj;
-    s.ci = s.x_oob ? (s.x_under ? 0 : dim_x - 1) : (int)fi;
-    s.cj = s.y_oob ? (s.y_under ? 0 : gdim_y - 1) : (int)fj;
-    return s;
-}
-
-// advect.h:62-70
-__device__ __forceinline__ float wall_discount(const SrcPos &s, float si, float sj, int dim_x,
-                                               int gdim_y)
-{
-    float factor = 1.0f;
-    if (s.x_oob) {
-        const float over = s.x_under ? -si : si - (float)(dim_x - 1);
-        factor *= (over < 0.5f) ? (1.0f - 2.0f * over) : 0.0f;
-    }
-    if (s.y_oob) {
-        const float over = s.y_under ? -sj : sj - (float)(gdim_y - 1);
-        factor *= (over < 0.5f) ? (1.0f - 2.0f * over) : 0.0f;
-    }
-    return factor;
-}
-
-// rows of p touched by a sample at s: [cj, cj + (y in range ? 1 : 0)]
-__device__ __forceinline__ bool rows_available(const SrcPos &s, int valid_begin, int valid_end)
-{
-    const int last = s.cj + (s.y_oob ? 0 : 1);
-    return s.cj >= valid_begin && last < valid_end;
-}
 
 // ---- advect<Vector2<float>, float>  (advect.h:24-85) ---------------------------------
 template <bool NO_SLIP>
@@ -105,49 +43,11 @@ advect_vec2f_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *
         if (halo_flag) atomicOr(halo_flag, 1);
         return;
     }
-    const size_t t = lcell(gs, s.ci, s.cj);
-    float2 r;
-    if (!s.x_oob && !s.y_oob) {
-        const float2 p11 = p[t], p12 = p[t + g.dim_x], p21 = p[t + 1], p22 = p[t + g.dim_x + 1];
-        r.x = mix1(s.di, mix1(s.dj, p11.x, p12.x), mix1(s.dj, p21.x, p22.x));
-        r.y = mix1(s.di, mix1(s.dj, p11.y, p12.y), mix1(s.dj, p21.y, p22.y));
-    } else {
-        if (s.x_oob && s.y_oob) {
-            r = p[t];
-        } else if (s.x_oob) {
-            const float2 a = p[t], b = p[t + g.dim_x];
-            r.x = mix1(s.dj, a.x, b.x);
-            r.y = mix1(s.dj, a.y, b.y);
-        } else {
-            const float2 a = p[t], b = p[t + 1];
-            r.x = mix1(s.di, a.x, b.x);
-            r.y = mix1(s.di, a.y, b.y);
-        }
-        if (NO_SLIP) {
-            const float f = wall_discount(s, si, sj, g.dim_x, g.gdim_y);
-            r.x = r.x * f;
-            r.y = r.y * f;
-        }
-    }
+    const float2 r = sample_global_vec2f<NO_SLIP>(p, gs, s, si, sj);
     next_p[c] = r;
 }
 
 // ---- advect<Vector3<UQ32>, float>  (advect.h:24-85 + uq32.h) ---------------------------
-struct uq3 {
-    uint32_t x, y, z;
-};
-
-__device__ __forceinline__ uq3 load_uq3(const uint32_t *p, size_t cell)
-{
-    const uint32_t *q = p + 3 * cell;
-    return {q[0], q[1], q[2]};
-}
-
-__device__ __forceinline__ uint32_t uq_mix(float t, uint32_t a, uint32_t b)
-{
-    return uq_narrow(mix1(t, uq_widen(a), uq_widen(b)));
-}
-
 // FUSE_GRAD: the projection step subtract_gradient (finitediff.cpp:41-82) is applied to the
 // cell's own velocity first -- the dye back-trace reads ONLY vel[ij] (advect.h:81), so the
 // projected velocity can be produced here, written back in place and used at once; this saves
@@ -184,35 +84,7 @@ advect_vec3uq32_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 
         if (halo_flag) atomicOr(halo_flag, 1);
         return;
     }
-    const size_t t = lcell(gs, s.ci, s.cj);
-    uq3 r;
-    if (!s.x_oob && !s.y_oob) {
-        const uq3 p11 = load_uq3(p, t), p12 = load_uq3(p, t + g.dim_x);
-        const uq3 p21 = load_uq3(p, t + 1), p22 = load_uq3(p, t + g.dim_x + 1);
-        r.x = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.x), uq_widen(p12.x)),
-                             mix1(s.dj, uq_widen(p21.x), uq_widen(p22.x))));
-        r.y = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.y), uq_widen(p12.y)),
-                             mix1(s.dj, uq_widen(p21.y), uq_widen(p22.y))));
-        r.z = uq_narrow(mix1(s.di, mix1(s.dj, uq_widen(p11.z), uq_widen(p12.z)),
-                             mix1(s.dj, uq_widen(p21.z), uq_widen(p22.z))));
-    } else {
-        // "T p_edge" narrows once (advect.h:45-54); returned raw when !no_slip (:57-59)
-        if (s.x_oob && s.y_oob) {
-            r = load_uq3(p, t);
-        } else if (s.x_oob) {
-            const uq3 a = load_uq3(p, t), b = load_uq3(p, t + g.dim_x);
-            r = {uq_mix(s.dj, a.x, b.x), uq_mix(s.dj, a.y, b.y), uq_mix(s.dj, a.z, b.z)};
-        } else {
-            const uq3 a = load_uq3(p, t), b = load_uq3(p, t + 1);
-            r = {uq_mix(s.di, a.x, b.x), uq_mix(s.di, a.y, b.y), uq_mix(s.di, a.z, b.z)};
-        }
-        if (NO_SLIP) {  // widen, scale, narrow again (advect.h:71)
-            const float f = wall_discount(s, si, sj, g.dim_x, g.gdim_y);
-            r.x = uq_narrow(uq_widen(r.x) * f);
-            r.y = uq_narrow(uq_widen(r.y) * f);
-            r.z = uq_narrow(uq_widen(r.z) * f);
-        }
-    }
+    const uq3 r = sample_global_uq3<NO_SLIP>(p, gs, s, si, sj);
     uint32_t *o = next_p + 3 * c;
     o[0] = r.x;
     o[1] = r.y;
@@ -435,6 +307,11 @@ inline dim3 grid_cells(int cells_per_row, int rows) { return dim3((cells_per_row
 
 }  // namespace
 
+static bool use_tiled_advect(int kernel, const Slab &g, int g_begin, int g_end)
+{
+    return kernel == 2 || (kernel == 0 && (int64_t)g.dim_x * (g_end - g_begin) >= kAdvectTiledMinCells);
+}
+
 hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, Slab g, int g_begin, int g_end,
                                   float dt)
 {
@@ -447,9 +324,12 @@ hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, S
 
 hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
                                Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
-                               float dt, bool no_slip, int *halo_flag, const Slab *src)
+                               float dt, bool no_slip, int *halo_flag, const Slab *src, int kernel)
 {
     if (g_end <= g_begin) return hipSuccess;
+    if (use_tiled_advect(kernel, g, g_begin, g_end))
+        return launch_advect_vec2f_tiled(s, next_p, p, vel, g, g_begin, g_end, valid_begin, valid_end, dt,
+                                         no_slip, halo_flag, src);
     const Slab gs = src ? *src : g;
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *o = reinterpret_cast<float2 *>(next_p);
@@ -467,9 +347,12 @@ hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, con
 hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                   const float *vel, Slab g, int g_begin, int g_end,
                                   int valid_begin, int valid_end, float dt, bool no_slip,
-                                  int *halo_flag, const Slab *src)
+                                  int *halo_flag, const Slab *src, int kernel)
 {
     if (g_end <= g_begin) return hipSuccess;
+    if (use_tiled_advect(kernel, g, g_begin, g_end))
+        return launch_advect_vec3uq32_tiled(s, next_p, p, const_cast<float *>(vel), nullptr, g, g_begin, g_end,
+                                            valid_begin, valid_end, dt, no_slip, halo_flag, 0.0f, src);
     const Slab gs = src ? *src : g;
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *vi = reinterpret_cast<float2 *>(const_cast<float *>(vel));  // read-only without FUSE_GRAD
@@ -485,9 +368,12 @@ hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_
 hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                           float *vel, const float *pressure, Slab g, int g_begin,
                                           int g_end, int valid_begin, int valid_end, float dt,
-                                          bool no_slip, int *halo_flag, float two_dx_inv)
+                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel)
 {
     if (g_end <= g_begin) return hipSuccess;
+    if (use_tiled_advect(kernel, g, g_begin, g_end))
+        return launch_advect_vec3uq32_tiled(s, next_p, p, vel, pressure, g, g_begin, g_end, valid_begin,
+                                            valid_end, dt, no_slip, halo_flag, two_dx_inv, nullptr);
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *vi = reinterpret_cast<float2 *>(vel);
     if (no_slip)

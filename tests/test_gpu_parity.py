@@ -736,3 +736,143 @@ def test_automatic_advection_halo_and_gather_fallback(sfl, oracle, nranks, dim_y
     reach = abs(vy) + 1
     thinnest = dim_y // nranks
     assert (expect == "gather") == (reach > 64 or reach > thinnest)
+
+
+def _smooth_velocity(dim_x, dim_y, amp):
+    """Solid-body swirl + a shear: neighbouring cells back-trace to neighbouring texels (what a
+    simulation has, as opposed to random_fields' per-cell noise)."""
+    j, i = np.mgrid[0:dim_y, 0:dim_x].astype(np.float32)
+    v = np.empty((dim_y, dim_x, 2), np.float32)
+    v[..., 0] = amp * (-(j - dim_y / 2) / max(dim_y, 2) + 0.3 * np.sin(i / 17.0))
+    v[..., 1] = amp * ((i - dim_x / 2) / max(dim_x, 2) + 0.3 * np.cos(j / 13.0))
+    return v
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("dim_x,dim_y", SHAPES + [(1000, 300), (129, 517), (2048, 65)])
+def test_both_advection_kernels_vs_oracle(sfl, oracle, kernel, dim_x, dim_y):
+    """SFL_OPT_ADVECT_KERNEL: the one-thread-per-cell gather (1) and the LDS-staged tiles (2) against the
+    oracle on noise (back-traces scattered over the window, many leaving it), on a smooth field (all inside
+    the window), on speeds far beyond the window (every sample from memory) and through a whole step."""
+    fields = [("noise", random_fields(dim_x, dim_y, 11, 100.0)[0]),
+              ("smooth", _smooth_velocity(dim_x, dim_y, 110.0)),
+              ("fast", random_fields(dim_x, dim_y, 12, 1500.0)[0]),
+              ("still", np.zeros((dim_y, dim_x, 2), np.float32))]
+    _, c, _ = random_fields(dim_x, dim_y, 13)
+    with sfl.Solver(dim_x, dim_y) as s:
+        s.set_option(sfl.capi.OPT_ADVECT_KERNEL, kernel)
+        assert s.get_option(sfl.capi.OPT_ADVECT_KERNEL) == kernel
+        for name, v in fields:
+            for ns in (True, False):
+                s.upload(sfl.capi.FIELD_VELOCITY, v)
+                s.upload(sfl.capi.FIELD_COLOR, c)
+                s.advect_color(DT, ns)
+                s.advect_velocity(DT, ns)
+                s.synchronize()
+                assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), oracle.advect_vec3uq32(c, v, DT, ns),
+                                 f"{name}: dye, no_slip {ns}")
+                assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), oracle.advect_vec2f(v, v, DT, ns),
+                                 f"{name}: velocity, no_slip {ns}")
+            for fused in (1, 0):
+                s.set_option(sfl.capi.OPT_FUSE_PROJECTION, fused)
+                s.upload(sfl.capi.FIELD_VELOCITY, v)
+                s.upload(sfl.capi.FIELD_COLOR, c)
+                s.step(DT, 1.0, 3, OMEGA)
+                s.synchronize()
+                want = oracle.step(v, c, DT, 1.0, 3, OMEGA)
+                assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), want[0], f"{name}: step velocity ({fused})")
+                assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), want[3], f"{name}: step colour ({fused})")
+
+
+def test_host_advect_of_another_field_on_a_tiled_size(hip, oracle):
+    """advect(next, q, v) with q != v (advect.h:74-76 allows it) at a size the automatic choice gives to the
+    tiled kernel: the cell's own velocity then comes from memory, the window holds q."""
+    v, _, _ = random_fields(320, 200, 21, 90.0)
+    q, _, _ = random_fields(320, 200, 22, 5.0)
+    for ns in (True, False):
+        assert_bit_equal(hip.advect_vec2f(q, v, DT, ns), oracle.advect_vec2f(q, v, DT, ns), f"other field, {ns}")
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("nranks,dim_y,halo", [(2, 100, 4), (3, 131, 7), (4, 64, 0)])
+def test_both_advection_kernels_on_slabs(sfl, oracle, kernel, nranks, dim_y, halo):
+    """The tiled kernel's window on a slab stops at the exchanged ghost rows (halo 0 = measured reach,
+    including the gathered whole field when the reach outruns a slab)."""
+    dim_x = 200
+    rng = np.random.default_rng(nranks)
+    v = np.empty((dim_y, dim_x, 2), np.float32)
+    v[..., 0] = rng.uniform(-100, 100, (dim_y, dim_x))
+    v[..., 1] = rng.uniform(-1, 1, (dim_y, dim_x)) * (30.0 * (halo - 1) if halo else 600.0)
+    _, c, _ = random_fields(dim_x, dim_y, 5)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_KERNEL, kernel)
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, halo)
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        slabs[0].advect_color(DT, False)
+        slabs[0].advect_velocity(DT, True)
+        slabs[0].synchronize()
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), oracle.advect_vec3uq32(c, v, DT, False), "dye")
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), oracle.advect_vec2f(v, v, DT, True), "velocity")
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, 0)   # the projected velocity may outrun a fixed halo
+        slabs[0].step(DT, 1.0, 4, OMEGA)
+        slabs[0].synchronize()
+        want = oracle.step(v, c, DT, 1.0, 4, OMEGA)
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), want[0], "step: velocity")
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), want[3], "step: colour")
+    finally:
+        for s in slabs:
+            s.close()
+
+
+@pytest.mark.parametrize("dim_x,dim_y", SHAPES + [(1000, 300), (129, 517), (2048, 65), (64, 32), (65, 33), (63, 31)])
+def test_step_with_fused_advection_and_divergence(sfl, oracle, dim_x, dim_y):
+    """SFL_OPT_FUSE_DIVERGENCE: sfl_step's velocity advection + calculate_divergence as ONE kernel (tile +
+    ring advected, differenced in LDS) against the oracle's step -- divergence field included -- on noise, a
+    smooth field and speeds beyond the window; with a queued force the two operators run separately (the
+    force lands between them, ino:264-269) and the step must still match."""
+    _, c, _ = random_fields(dim_x, dim_y, 31)
+    fields = [("noise", random_fields(dim_x, dim_y, 32, 100.0)[0]), ("smooth", _smooth_velocity(dim_x, dim_y, 120.0)),
+              ("fast", random_fields(dim_x, dim_y, 33, 900.0)[0])]
+    with sfl.Solver(dim_x, dim_y) as s:
+        s.set_option(sfl.capi.OPT_ADVECT_KERNEL, 2)
+        assert s.get_option(sfl.capi.OPT_FUSE_DIVERGENCE) == 1
+        for name, v in fields:
+            want = oracle.step(v, c, DT, 1.0, 3, OMEGA)
+            for fused in (1, 0):
+                s.set_option(sfl.capi.OPT_FUSE_DIVERGENCE, fused)
+                s.upload(sfl.capi.FIELD_VELOCITY, v)
+                s.upload(sfl.capi.FIELD_COLOR, c)
+                s.step(DT, 1.0, 3, OMEGA)
+                s.synchronize()
+                for field, k in ((sfl.capi.FIELD_DIVERGENCE, 1), (sfl.capi.FIELD_VELOCITY, 0),
+                                 (sfl.capi.FIELD_PRESSURE, 2), (sfl.capi.FIELD_COLOR, 3)):
+                    assert_bit_equal(s.download(field), want[k], f"{name}: field {field}, fused {fused}")
+        # a drag force between advection and divergence
+        s.set_option(sfl.capi.OPT_FUSE_DIVERGENCE, 1)
+        v = fields[0][1]
+        cells = np.array([[dim_x // 2, dim_y // 2], [0, 0]], np.int32)
+        vel = np.array([[55.0, -35.0], [-20.0, 10.0]], np.float32)
+        s.upload(sfl.capi.FIELD_VELOCITY, v)
+        s.upload(sfl.capi.FIELD_COLOR, c)
+        s.queue_forces(cells, vel)
+        s.step(DT, 1.0, 3, OMEGA)
+        s.step(DT, 1.0, 3, OMEGA)      # and a fused one right after it
+        s.synchronize()
+        v1 = oracle.advect_vec2f(v, v, DT, True)
+        for (ci, cj), f in zip(cells, vel):
+            v1[cj, ci] = f
+        d = oracle.divergence(v1, 1.0)
+        p = oracle.poisson_solve(d, 1.0, 3, OMEGA)
+        v1 = oracle.subtract_gradient(v1, p, 1.0)
+        c1 = oracle.advect_vec3uq32(c, v1, DT, False)
+        want = oracle.step(v1, c1, DT, 1.0, 3, OMEGA)
+        assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), want[0], "after a forced step + a fused step: velocity")
+        assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), want[3], "after a forced step + a fused step: colour")
