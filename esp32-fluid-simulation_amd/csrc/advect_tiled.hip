@@ -14,8 +14,6 @@
 // Numerics contract: -ffp-contract=off, every operation individually rounded in the
 // reference's order (advect_math.h).  Reference citations are file:line under
 // /root/reference/ESP32-fluid-simulation/.
-#include <stdlib.h>
-
 #include "advect_math.h"
 #include "kernels.h"
 
@@ -24,6 +22,8 @@ namespace {
 
 using namespace advect_math;
 
+// Measured at 8192^2 (tools/r02_runs/r02_run26.sh): tiles of 16 / 32 / 64 rows 188 / 190 / 235 us (velocity),
+// margins of 2 / 4 / 6 cells 209 / 190 / 194 us on per-cell noise of +-3.3 cells -- 32 rows, 4 cells.
 constexpr int kTX = 64, kTY = 32;        // output cells of a tile
 constexpr int kR = 4;                    // margin of the staged window (cells)
 constexpr int kSX = kTX + 2 * kR, kSY = kTY + 2 * kR;
@@ -361,11 +361,10 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
     }
 }
 
-int threads_env(int fallback)
-{
-    static const int v = [] { const char *e = getenv("SFL_ADVECT_THREADS"); return e ? atoi(e) : 0; }();
-    return v == 256 || v == 512 ? v : fallback;
-}
+// threads per block: the dye kernel's window takes 34.5 KB of LDS (4 blocks per CU), so it needs 8 waves
+// per block to fill a CU (392 us at 8192^2 against 404 with 4); the velocity kernel's 23 KB leave room
+// for 6 blocks of 4 waves (193 us either way)
+constexpr int kThreadsVec2 = 256, kThreadsDye = 512;
 
 TileGrid tile_grid(int dim_x, int rows)
 {
@@ -385,19 +384,14 @@ hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *
     if (g_end <= g_begin) return hipSuccess;
     const Slab gs = src ? *src : g;
     const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
-    const int threads = threads_env(256);
-    const dim3 grid(tg.per_xcd * kXcds), block(threads);
+    const dim3 grid(tg.per_xcd * kXcds), block(kThreadsVec2);
     auto *o = reinterpret_cast<float2 *>(next_p);
     auto *pi = reinterpret_cast<const float2 *>(p);
     auto *vi = reinterpret_cast<const float2 *>(vel);
     const bool self = p == vel && !src;
-#define SFL_GO(NS_, SELF_)                                                                                 \
-    if (threads == 512)                                                                                    \
-        advect_vec2f_tiled_kernel<NS_, SELF_, 512><<<grid, block, 0, s>>>(o, pi, vi, g, gs, tg, g_begin, g_end, \
-                                                                         valid_begin, valid_end, dt, halo_flag); \
-    else                                                                                                   \
-        advect_vec2f_tiled_kernel<NS_, SELF_, 256><<<grid, block, 0, s>>>(o, pi, vi, g, gs, tg, g_begin, g_end, \
-                                                                         valid_begin, valid_end, dt, halo_flag)
+#define SFL_GO(NS_, SELF_)                                                                 \
+    advect_vec2f_tiled_kernel<NS_, SELF_, kThreadsVec2><<<grid, block, 0, s>>>(            \
+        o, pi, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag)
     if (no_slip) {
         if (self) { SFL_GO(true, true); } else { SFL_GO(true, false); }
     } else {
@@ -415,16 +409,11 @@ hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const u
     if (g_end <= g_begin) return hipSuccess;
     const Slab gs = src ? *src : g;
     const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
-    const int threads = threads_env(512);
-    const dim3 grid(tg.per_xcd * kXcds), block(threads);
+    const dim3 grid(tg.per_xcd * kXcds), block(kThreadsDye);
     auto *vi = reinterpret_cast<float2 *>(vel);
 #define SFL_GO(NS_, FG_)                                                                                    \
-    if (threads == 512)                                                                                     \
-        advect_vec3uq32_tiled_kernel<NS_, FG_, 512><<<grid, block, 0, s>>>(                                 \
-            next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv); \
-    else                                                                                                    \
-        advect_vec3uq32_tiled_kernel<NS_, FG_, 256><<<grid, block, 0, s>>>(                                 \
-            next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv)
+    advect_vec3uq32_tiled_kernel<NS_, FG_, kThreadsDye><<<grid, block, 0, s>>>(                             \
+        next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv)
     if (no_slip) {
         if (pressure) { SFL_GO(true, true); } else { SFL_GO(true, false); }
     } else {
