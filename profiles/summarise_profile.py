@@ -21,6 +21,12 @@ def short(name):
         nt = m.group(1) == "2" and len(flags) >= 3 and flags[2]
         return (f"sor_fused_kernel<Lane{m.group(1)}{'nt' if nt else ''}, NS={m.group(2)}, dx1={m.group(4)}, "
                 f"zero_in={m.group(5)}>")
+    m = re.search(r"(advect_divergence_tiled_kernel|advect_vec2f_tiled_kernel|advect_vec3uq32_tiled_kernel)<([^>]*)>", name)
+    if m:
+        flags = re.findall(r"true|false", m.group(2))
+        label = {"advect_divergence_tiled_kernel": ["no_slip"], "advect_vec2f_tiled_kernel": ["no_slip", "self"],
+                 "advect_vec3uq32_tiled_kernel": ["no_slip", "fuse_grad"]}[m.group(1)]
+        return m.group(1) + "<" + ", ".join(f"{a}={b}" for a, b in zip(label, flags)) + ">"
     for key in ("divergence_stream_kernel", "gradient_stream_kernel", "sor_half_sweep_kernel", "advect_vec2f_kernel", "advect_vec3uq32_kernel",
                 "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):
         if key in name:
