@@ -524,6 +524,10 @@ def run_rank(args):
             "parity": parity,
             "roofline": roofline,
             "sim_steps_per_sec": sim_sps,
+            "sim_step_us": (1e6 / sim_sps) if sim_sps else None,
+            "sim_step_kernels": ("inside sfl_step advect_velocity + calculate_divergence run as one kernel and "
+                                 "subtract_gradient + advect_color as one (per-kernel times: "
+                                 "profiles/r02_sim_step_kernel_trace.txt); the operators below are timed one by one"),
             "sim_step_per_operator": op_us,
             **({"sim_steps_note": sim_note} if sim_note else {}),
             "device": name,
