@@ -261,6 +261,119 @@ advect_divergence_tiled_kernel(float2 *__restrict__ next_v, float *__restrict__ 
     }
 }
 
+// ---- calculate_divergence (finitediff.cpp:9-39) and subtract_gradient (finitediff.cpp:41-82) as tiles ----------
+// Stand-alone operators (inside sfl_step both are fused into the advections above).  Same tile, window margin 1:
+// the 66 x 34 window of v (divergence) / of p (gradient) is staged in LDS, all loads of a block in flight at once.
+constexpr int kFX = kTX + 2, kFY = kTY + 2;
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+divergence_tiled_kernel(float *__restrict__ div, const float2 *__restrict__ v, Slab g, TileGrid tg, int g_begin,
+                        int g_end, float two_dx_inv)
+{
+    constexpr int kWaves = THREADS / 64, kRows = kTY / kWaves;
+    constexpr int kLoads = (kFX * kFY + THREADS - 1) / THREADS;
+    __shared__ float2 win[kFY * kFX];
+    int tx, ty;
+    if (!tile_of_block(tg, tx, ty)) return;
+    const int x0 = tx * kTX, y0 = g_begin + ty * kTY;
+    const Window w = window_of<1>(x0, y0, g, g.grow0, g.grow0 + g.lrows);
+    {
+        float2 got[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            got[k] = window_has<kFX>(w, e) ? v[window_cell<kFX>(w, g, e)] : float2{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            if (e < kFX * kFY) win[e] = got[k];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = x0 + lane;
+    if (i >= g.dim_x) return;
+    const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int gj = y0 + wave + kWaves * r;
+        if (gj >= g_end) break;
+        const float2 *q = win + (gj - w.sy0) * kFX + (i - w.sx0);
+        float s;
+        if (i > 0 && i < i_max && gj > 0 && gj < j_max) {  // div_expr_fast, :29
+            const float hx = -q[-1].x + q[1].x;
+            const float hy = -q[-kFX].y + q[kFX].y;
+            s = hx + hy;
+        } else {  // div_expr_safe, :15-20: ghost velocity = -own
+            const float2 own = q[0];
+            s = 0.0f;
+            s += (i > 0) ? -q[-1].x : own.x;
+            s += (i < i_max) ? q[1].x : -own.x;
+            s += (gj > 0) ? -q[-kFX].y : own.y;
+            s += (gj < j_max) ? q[kFX].y : -own.y;
+        }
+        div[lcell(g, i, gj)] = s * two_dx_inv;
+    }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+gradient_tiled_kernel(float2 *v, const float *__restrict__ p, Slab g, TileGrid tg, int g_begin, int g_end,
+                      float two_dx_inv)
+{
+    constexpr int kWaves = THREADS / 64, kRows = kTY / kWaves;
+    constexpr int kLoads = (kFX * kFY + THREADS - 1) / THREADS;
+    __shared__ float win[kFY * kFX];
+    int tx, ty;
+    if (!tile_of_block(tg, tx, ty)) return;
+    const int x0 = tx * kTX, y0 = g_begin + ty * kTY;
+    const Window w = window_of<1>(x0, y0, g, g.grow0, g.grow0 + g.lrows);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = x0 + lane;
+    const bool column = i < g.dim_x;
+    float2 own[kRows];
+    {
+        float got[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            got[k] = window_has<kFX>(w, e) ? p[window_cell<kFX>(w, g, e)] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const int gj = y0 + wave + kWaves * r;
+            own[r] = (column && gj < g_end) ? v[lcell(g, i, gj)] : float2{0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            if (e < kFX * kFY) win[e] = got[k];
+        }
+    }
+    __syncthreads();
+    if (!column) return;
+    const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int gj = y0 + wave + kWaves * r;
+        if (gj >= g_end) break;
+        const float *q = win + (gj - w.sy0) * kFX + (i - w.sx0);
+        const float pc = q[0];
+        const float pw = (i > 0) ? q[-1] : pc;      // finitediff.cpp:47-69: a missing neighbour is the cell itself
+        const float pe = (i < i_max) ? q[1] : pc;
+        const float ps = (gj > 0) ? q[-kFX] : pc;
+        const float pn = (gj < j_max) ? q[kFX] : pc;
+        const float gx = (pe - pw) * two_dx_inv;
+        const float gy = (pn - ps) * two_dx_inv;
+        float2 u = own[r];
+        u.x = u.x - gx;
+        u.y = u.y - gy;
+        v[lcell(g, i, gj)] = u;
+    }
+}
+
 // ---- advect<Vector3<UQ32>, float>  (advect.h:24-85 + uq32.h) -------------------------------------
 // The window holds the three channels in three planes (4-byte LDS accesses, no 12-byte alignment
 // question).  FUSE_GRAD as in stencil_kernels.hip: the projection of the cell's own velocity
@@ -434,6 +547,26 @@ hipError_t launch_advect_divergence_tiled(hipStream_t s, float *next_v, float *d
         advect_divergence_tiled_kernel<true, 512><<<grid, block, 0, s>>>(o, div, vi, g, tg, dt, two_dx_inv);
     else
         advect_divergence_tiled_kernel<false, 512><<<grid, block, 0, s>>>(o, div, vi, g, tg, dt, two_dx_inv);
+    return hipGetLastError();
+}
+
+hipError_t launch_divergence_tiled(hipStream_t s, float *div, const float *v, Slab g, int g_begin, int g_end,
+                                   float two_dx_inv)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
+    divergence_tiled_kernel<256><<<dim3(tg.per_xcd * kXcds), dim3(256), 0, s>>>(
+        div, reinterpret_cast<const float2 *>(v), g, tg, g_begin, g_end, two_dx_inv);
+    return hipGetLastError();
+}
+
+hipError_t launch_gradient_tiled(hipStream_t s, float *v, const float *p, Slab g, int g_begin, int g_end,
+                                 float two_dx_inv)
+{
+    if (g_end <= g_begin) return hipSuccess;
+    const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
+    gradient_tiled_kernel<256><<<dim3(tg.per_xcd * kXcds), dim3(256), 0, s>>>(reinterpret_cast<float2 *>(v), p, g, tg,
+                                                                            g_begin, g_end, two_dx_inv);
     return hipGetLastError();
 }
 

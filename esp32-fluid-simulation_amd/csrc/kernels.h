@@ -66,19 +66,16 @@ hipError_t launch_advect_divergence_tiled(hipStream_t s, float *next_v, float *d
                                           float dt, bool no_slip, float two_dx_inv);
 
 // ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
+// `kernel` as for the advections: 1 = one thread per cell (stencil_kernels.hip), 2 = the 66 x 34 window of a
+// 64 x 32-cell tile staged in LDS (advect_tiled.hip), 0 = automatic (2 from kAdvectTiledMinCells cells).
 hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
-                             int g_end, float two_dx_inv);
+                             int g_end, float two_dx_inv, int kernel = 0);
 hipError_t launch_subtract_gradient(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
-                                    int g_end, float two_dx_inv);
-
-// Row-streaming variants (stream_stencils.hip): dim_x even, 16-byte aligned arrays.  The two
-// launchers above pick them automatically when applicable (SFL_STENCIL_BASELINE=1 in the
-// environment forces the one-thread-per-cell kernels, for A/B measurements).
-bool stream_stencils_applicable(const Slab &g, const void *a, const void *b);
-hipError_t launch_divergence_stream(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
-                                    int g_end, float two_dx_inv);
-hipError_t launch_gradient_stream(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
-                                  int g_end, float two_dx_inv);
+                                    int g_end, float two_dx_inv, int kernel = 0);
+hipError_t launch_divergence_tiled(hipStream_t s, float *div, const float *v, Slab g, int g_begin, int g_end,
+                                   float two_dx_inv);
+hipError_t launch_gradient_tiled(hipStream_t s, float *v, const float *p, Slab g, int g_begin, int g_end,
+                                 float two_dx_inv);
 
 // ---- red-black SOR (poisson.cpp:14-112) ------------------------------------------------
 struct SorParams {

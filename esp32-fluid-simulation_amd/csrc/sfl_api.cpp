@@ -1208,7 +1208,8 @@ int sfl_calculate_divergence(sfl_context *ctx, float dx)
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
-        HIP_TRY(sfl::launch_divergence(c->stream, c->div, c->vel, c->geom, c->g0, c->g1, two_dx_inv));
+        HIP_TRY(sfl::launch_divergence(c->stream, c->div, c->vel, c->geom, c->g0, c->g1, two_dx_inv,
+                                       c->opt_advect_kernel));
     }
     return SFL_OK;
 }
@@ -1232,7 +1233,7 @@ int sfl_subtract_gradient(sfl_context *ctx, float dx)
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(sfl::launch_subtract_gradient(c->stream, c->vel, c->p, c->geom, c->g0, c->g1,
-                                              two_dx_inv));
+                                              two_dx_inv, c->opt_advect_kernel));
     }
     return SFL_OK;
 }

@@ -7,8 +7,6 @@
 // expressions such as `0.0f + w` (it maps -0 to +0) or reassociate sums.
 //
 // Reference citations are file:line under /root/reference/ESP32-fluid-simulation/.
-#include <stdlib.h>
-
 #include "advect_math.h"
 #include "kernels.h"
 
@@ -307,6 +305,7 @@ inline dim3 grid_cells(int cells_per_row, int rows) { return dim3((cells_per_row
 
 }  // namespace
 
+// the tiled kernels (advect_tiled.hip) or the one-thread-per-cell ones of this file?
 static bool use_tiled_advect(int kernel, const Slab &g, int g_begin, int g_end)
 {
     return kernel == 2 || (kernel == 0 && (int64_t)g.dim_x * (g_end - g_begin) >= kAdvectTiledMinCells);
@@ -385,29 +384,23 @@ hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const
     return hipGetLastError();
 }
 
-static bool force_baseline_stencils()
-{
-    static const bool on = [] { const char *e = getenv("SFL_STENCIL_BASELINE"); return e && e[0] == '1'; }();
-    return on;
-}
-
 hipError_t launch_divergence(hipStream_t s, float *div, const float *v, Slab g, int g_begin,
-                             int g_end, float two_dx_inv)
+                             int g_end, float two_dx_inv, int kernel)
 {
     if (g_end <= g_begin) return hipSuccess;
-    if (!force_baseline_stencils() && stream_stencils_applicable(g, div, v))
-        return launch_divergence_stream(s, div, v, g, g_begin, g_end, two_dx_inv);
+    if (use_tiled_advect(kernel, g, g_begin, g_end))
+        return launch_divergence_tiled(s, div, v, g, g_begin, g_end, two_dx_inv);
     divergence_kernel<<<grid_cells(g.dim_x, g_end - g_begin), kBlock, 0, s>>>(
         div, reinterpret_cast<const float2 *>(v), g, g_begin, two_dx_inv);
     return hipGetLastError();
 }
 
 hipError_t launch_subtract_gradient(hipStream_t s, float *v, const float *p, Slab g, int g_begin,
-                                    int g_end, float two_dx_inv)
+                                    int g_end, float two_dx_inv, int kernel)
 {
     if (g_end <= g_begin) return hipSuccess;
-    if (!force_baseline_stencils() && stream_stencils_applicable(g, v, p))
-        return launch_gradient_stream(s, v, p, g, g_begin, g_end, two_dx_inv);
+    if (use_tiled_advect(kernel, g, g_begin, g_end))
+        return launch_gradient_tiled(s, v, p, g, g_begin, g_end, two_dx_inv);
     subtract_gradient_kernel<<<grid_cells(g.dim_x, g_end - g_begin), kBlock, 0, s>>>(
         reinterpret_cast<float2 *>(v), p, g, g_begin, two_dx_inv);
     return hipGetLastError();

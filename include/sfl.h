@@ -84,10 +84,10 @@ extern "C" {
                                      on a second stream, overlapped with the rows of the
                                      neighbouring launches that do not depend on them (cut-adjacent
                                      rows first / last); 0 = every launch whole, exchanges in line */
-#define SFL_OPT_ADVECT_KERNEL 9   /* advection kernels: 0 = auto, 1 = one thread per cell gathering
-                                     its four texels from memory, 2 = the source window of a
-                                     64 x 32-cell tile staged in LDS (auto = 2 from 16384 cells per
-                                     launch); same results                                        */
+#define SFL_OPT_ADVECT_KERNEL 9   /* advection, divergence and gradient kernels: 0 = auto, 1 = one
+                                     thread per cell reading its neighbours / texels from memory,
+                                     2 = the window of a 64 x 32-cell tile staged in LDS (auto = 2
+                                     from 16384 cells per launch); same results                  */
 #define SFL_OPT_FUSE_DIVERGENCE 10 /* sfl_step only: 1 (default) = on a whole-domain context with no
                                      queued forces and advection kernel 2, the velocity advection
                                      and calculate_divergence run as one kernel (the advected tile

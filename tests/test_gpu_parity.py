@@ -758,7 +758,7 @@ def test_both_advection_kernels_vs_oracle(sfl, oracle, kernel, dim_x, dim_y):
               ("smooth", _smooth_velocity(dim_x, dim_y, 110.0)),
               ("fast", random_fields(dim_x, dim_y, 12, 1500.0)[0]),
               ("still", np.zeros((dim_y, dim_x, 2), np.float32))]
-    _, c, _ = random_fields(dim_x, dim_y, 13)
+    _, c, pr = random_fields(dim_x, dim_y, 13)
     with sfl.Solver(dim_x, dim_y) as s:
         s.set_option(sfl.capi.OPT_ADVECT_KERNEL, kernel)
         assert s.get_option(sfl.capi.OPT_ADVECT_KERNEL) == kernel
@@ -773,6 +773,15 @@ def test_both_advection_kernels_vs_oracle(sfl, oracle, kernel, dim_x, dim_y):
                                  f"{name}: dye, no_slip {ns}")
                 assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), oracle.advect_vec2f(v, v, DT, ns),
                                  f"{name}: velocity, no_slip {ns}")
+            # the finite-difference operators follow the same option (tiled / one thread per cell)
+            s.upload(sfl.capi.FIELD_VELOCITY, v)
+            s.upload(sfl.capi.FIELD_PRESSURE, pr)
+            s.calculate_divergence(0.5)
+            s.subtract_gradient(0.5)
+            s.synchronize()
+            assert_bit_equal(s.download(sfl.capi.FIELD_DIVERGENCE), oracle.divergence(v, 0.5), f"{name}: divergence")
+            assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), oracle.subtract_gradient(v, pr, 0.5),
+                             f"{name}: gradient")
             for fused in (1, 0):
                 s.set_option(sfl.capi.OPT_FUSE_PROJECTION, fused)
                 s.upload(sfl.capi.FIELD_VELOCITY, v)
