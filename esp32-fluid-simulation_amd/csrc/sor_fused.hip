@@ -82,7 +82,9 @@ template <int NS, bool VEC, bool ZERO_IN, bool NT = false>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
-    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 6;
+        // three rows in flight ahead of the pipeline: six cost 12 more VGPRs (and, with the rhs read-ahead, spills
+    // at NS = 16) without being faster (profiles/r02_rhs_read_ahead.txt)
+    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 3;
     // LDS per wave: the rhs ring (RING rows x 2 planes x 64 lanes x 4 B)
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
@@ -177,6 +179,7 @@ struct Lane2 : WaveCommon {
     {
         ring[(slot * 2 + plane) * 64] = x;
     }
+    __device__ __forceinline__ void pin() const { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ V ring_load(int slot, int plane) const
     {
         return ring[(slot * 2 + plane) * 64];

@@ -126,6 +126,7 @@ SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, t
 // tile at NS = 12).  Leaving a pass out keeps an older version in the row's register; by the
 // same inequality nothing that is needed ever reads it.  The tile may start one row earlier
 // (even alignment), which only makes J an over-estimate.
+constexpr int kRhsAhead = 1;    // stages between the LDS read of a right-hand-side pair and its use
 constexpr int kSteadyTrip = 2;  // TRIP = 0, 1: prologue trips; kSteadyTrip: every pass runs
 constexpr bool pass_runs(int trip, int ring, int u, int s)
 {
@@ -141,7 +142,7 @@ constexpr int prologue_trips(int ns) { return (2 * ns + ring_rows(ns) - 1) / rin
 // compiled, eight SGPR spill moves for its buffer descriptor.)
 constexpr bool steady_rows_are_output(int ns) { return prologue_trips(ns) * ring_rows(ns) >= 2 * ns + 1; }
 
-// The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod 6)
+// The work of ONE pipeline iteration: input row y (already waiting in prefetch slot U mod kPrefetch)
 // enters, row y - NS leaves.  U = (y - y_start) mod RING is a compile-time constant.
 // FLIP: the tile is streamed TOP-DOWN (the backend maps pipeline row index t to domain row -t, same
 // parity): the pipeline's "previous row" is then the N neighbour and its "next row" the S neighbour,
@@ -183,8 +184,27 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     //   E[r] = E_m (previous iteration), E[r - 1] = E_m (stage m + 1 comes later).  So every
     //   relaxation reads exactly the versions the reference's in-place sweep reads
     //   (poisson.cpp:14-61), and may overwrite its own input register.
+    // The right-hand sides of a stage are read from the LDS ring ONE STAGE AHEAD of their use: the
+    // relaxations of an iteration form one dependency chain (every pass needs the previous pass's result of
+    // the same iteration as its S / N operand), all waves of a launch are resident at once, so a launch lasts
+    // as long as that chain -- and an LDS read issued right in front of its use (what the compiler does to
+    // save a register pair) puts the LDS latency on the chain once per stage.  d_e / d_o[m + 1] are
+    // requested while stage m computes; bk.pin() keeps the compiler from sinking the reads back down.
+    // Measured (profiles/r02_rhs_read_ahead.txt): 8192^2 x 80 1.94 -> 1.89 ms, 8192 x 2048 0.597 -> 0.556 ms.
+    constexpr int kAhead = kRhsAhead;
+    V d_e[NS / 2 + 1], d_o[NS / 2 + 1];            // (only kAhead + 1 of each alive at a time)
+#pragma unroll
+    for (int m = 1; m <= kAhead && m <= NS / 2; ++m) {
+        d_e[m] = bk.ring_load(wrapn(U - (2 * m - 1), RING), 0);
+        d_o[m] = bk.ring_load(wrapn(U - 2 * m, RING), 1);
+    }
 #pragma unroll
     for (int m = 1; m <= NS / 2; ++m) {
+        if (m + kAhead <= NS / 2) {
+            d_e[m + kAhead] = bk.ring_load(wrapn(U - (2 * (m + kAhead) - 1), RING), 0);
+            d_o[m + kAhead] = bk.ring_load(wrapn(U - 2 * (m + kAhead), RING), 1);
+            bk.pin();
+        }
         // ---- E_m of row y - (2m - 1) ----
         if (pass_runs(TRIP, RING, U, 2 * m - 1)) {
             const int lag = 2 * m - 1;
@@ -196,7 +216,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V oc = pp.O[i0];
             const V w = ev ? bk.from_lower_lane(oc) : oc;
             const V e = ev ? oc : bk.from_upper_lane(oc);
-            const V d = bk.ring_load(i0, 0);
+            const V d = d_e[m];
             const RowFacts rf = bk.row_facts(r);
             pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[FLIP ? ip : im], pp.O[FLIP ? im : ip], d,
                                            ev ? eca : ecb, rf);
@@ -212,7 +232,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V oc = pp.E[i0];
             const V w = ev ? oc : bk.from_lower_lane(oc);
             const V e = ev ? bk.from_upper_lane(oc) : oc;
-            const V d = bk.ring_load(i0, 1);
+            const V d = d_o[m];
             const RowFacts rf = bk.row_facts(r);
             const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[FLIP ? ip : im], pp.E[FLIP ? im : ip], d,
                                               ev ? ecb : eca, rf);

@@ -43,7 +43,7 @@ EMU_BINOP(*)
 struct EmuBackend {
     using V = V64;
     using M = M64;
-    static constexpr int kPrefetch = 6;
+    static constexpr int kPrefetch = 3;
 
     const float *p_in;
     const float *d;
@@ -155,6 +155,7 @@ struct EmuBackend {
         return r;
     }
     V detach(const V &x) const { return x; }
+    void pin() const {}
 };
 
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
