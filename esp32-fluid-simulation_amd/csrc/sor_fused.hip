@@ -186,8 +186,12 @@ struct Lane2 : WaveCommon {
     }
 };
 
+// Occupancy the register allocator must keep: a launch lasts as long as one wave's chain of iterations, and
+// that chain is served best with >= 3 waves on the SIMD (NS >= 12: 168 VGPRs) / 4 (NS <= 10: 128).
+constexpr int min_waves_per_simd(int ns) { return ns >= 12 ? 3 : 4; }
+
 template <class B, int NS, bool DX1, bool ZERO_IN>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t1,
                  sor::Tiling t2, SorParams prm)
 {
