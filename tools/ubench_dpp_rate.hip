@@ -192,6 +192,30 @@ __global__ void k_relax_two_chains(float *o, float s, long long *cyc)
     stamp(cyc, t0);
 }
 
+// the wave shift through the LDS crossbar instead of DPP: ds_bpermute_b32 issued one relaxation ahead of its use
+// (9 instructions per relaxation: bpermute + plain add instead of the DPP add), no DPP instruction in the stream
+#define RELAX_BP(TNOW, TNEXT, CNT)                                                                    \
+    "ds_bpermute_b32 " TNEXT ", %8, %4\n"                                                             \
+    "s_waitcnt lgkmcnt(" CNT ")\n"                                                                    \
+    "v_add_f32 " TNOW ", " TNOW ", %4\n"                                                              \
+    "v_add_f32 " TNOW ", " TNOW ", %0\n v_add_f32 " TNOW ", %5, " TNOW "\n v_sub_f32 " TNOW ", %6, " TNOW "\n" \
+    "v_mul_f32 " TNOW ", 0x3e800000, " TNOW "\n v_mul_f32 %3, %9, %7\n v_mul_f32 " TNOW ", %9, " TNOW "\n v_sub_f32 %0, %3, " TNOW "\n"
+__global__ void k_relax_bpermute(float *o, float s, long long *cyc)
+{
+    const long long t0 = clock64();
+    float oc = threadIdx.x, nn = s, d = 0.5f, own = 2.0f, x = 1.0f, ta = 0.0f, tb = 0.0f, u;
+    const int addr = ((threadIdx.x + 1) & 63) * 4;
+    for (int i = 0; i < ITER; ++i)
+        asm volatile(
+            RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1") RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1")
+            RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1") RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1")
+            RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1") RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1")
+            RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1") RELAX_BP("%1", "%2", "1") RELAX_BP("%2", "%1", "1")
+            : "+v"(x), "+v"(ta), "+v"(tb), "=&v"(u) : "v"(oc), "v"(nn), "v"(d), "v"(own), "v"(addr), "s"(s) : "memory");
+    o[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    stamp(cyc, t0);
+}
+
 template <class K>
 void run(const char *name, K k, int waves_per_simd, int insts_per_iter, float *o, long long *cyc)
 {
@@ -230,6 +254,7 @@ int main()
         run("dpp in every 2nd relax", k_relax_half, w, 128, o, cyc);
         run("dpp in every 4th relax", k_relax_quarter, w, 128, o, cyc);
         run("two chains, dpp in one", k_relax_two_chains, w, 256, o, cyc);
+        run("relaxation, ds_bpermute", k_relax_bpermute, w, 16 * 8, o, cyc);   // per 8 "useful" instructions: compare with the chains
     }
     return 0;
 }
