@@ -885,3 +885,24 @@ def test_step_with_fused_advection_and_divergence(sfl, oracle, dim_x, dim_y):
         want = oracle.step(v1, c1, DT, 1.0, 3, OMEGA)
         assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), want[0], "after a forced step + a fused step: velocity")
         assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), want[3], "after a forced step + a fused step: colour")
+
+
+@pytest.mark.parametrize("fuse", [2, 4, 6, 8, 10, 12, 14, 16])
+def test_every_fuse_depth_from_zero_and_continuing(sfl, oracle, fuse):
+    """Each compiled depth of the fused kernel, first launch (p implicitly zero) and continuing launches, interior /
+    flipped / boundary tiles, dx = 1 and dx != 1, on a grid large enough for several tiles per strip (the register
+    allocation differs per depth: NS = 14 is held at three waves per SIMD with a few spilled registers)."""
+    dim_x, dim_y = 1500, 1100
+    _, _, d = random_fields(dim_x, dim_y, 40 + fuse)
+    iters = fuse + fuse // 2          # three launches of this depth
+    for dx in (1.0, 0.75):
+        with sfl.Solver(dim_x, dim_y) as s:
+            s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
+            s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+            s.poisson_solve(dx, iters, OMEGA)
+            s.synchronize()
+            info = s.last_solve_info()
+            got = s.download(sfl.capi.FIELD_PRESSURE)
+        assert info["fuse"] == fuse and info["launches"] == 3
+        assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"fuse {fuse} dx {dx}")
