@@ -18,6 +18,7 @@ OPT_FUSE_PROJECTION = 7
 OPT_SOR_OVERLAP = 8
 OPT_ADVECT_KERNEL = 9
 OPT_FUSE_DIVERGENCE = 10
+OPT_SMALL_GRID = 11
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 

@@ -107,6 +107,31 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
                             Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells);
 
+// ---- small grids: one workgroup, fields in LDS (small_grid.hip) -------------------------------------
+// WHOLE-DOMAIN arrays of dim_x * dim_y <= kSmallGridMaxCells cells (16 B of LDS per cell: 96 KB of the CU's 160;
+// beyond ~6 K cells one CU is slower than the general kernels on all of them, measured).
+constexpr int kSmallGridMaxCells = 6144;
+bool small_grid_fits(int dim_x, int dim_y);   // few enough cells, and few enough of one colour per thread
+// poisson_solve (poisson.cpp:114-125): p = iters red-black SOR iterations from zero on rhs d, one launch.
+hipError_t launch_small_solve(hipStream_t s, float *p, const float *d, int dim_x, int dim_y, int iters, SorParams prm);
+// One whole step (ino:252-287): advect v (no-slip) -> forces -> divergence -> solve -> projection -> advect
+// dye (free-slip), one launch.  v_out / col_out must not alias the inputs; div and p receive the step's
+// divergence and pressure.  n_forces (cell, velocity) pairs as for launch_apply_forces, applied in order.
+struct SmallStep {
+    const float *v_in;
+    float *v_out;
+    const uint32_t *col_in;
+    uint32_t *col_out;
+    float *div, *p;
+    int dim_x, dim_y, iters;
+    float dt, two_dx_inv;
+    SorParams prm;
+    const int *force_cells;
+    const float *force_vel;
+    int n_forces;
+};
+hipError_t launch_small_step(hipStream_t s, const SmallStep &a);
+
 // Fill rows [g_begin, g_end) of a float field with zero (poisson.cpp:117-119).
 hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_end);
 

@@ -133,7 +133,7 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1;
 
     ncclComm_t comm = nullptr;
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
@@ -332,6 +332,16 @@ int effective_fuse(const sfl_context *c)
 }
 
 int effective_kernel(const sfl_context *c) { return c->opt_sor_kernel == 1 ? 1 : 2; }
+
+// One workgroup, fields in LDS (small_grid.hip): whole-domain contexts of at most kSmallGridMaxCells cells whose
+// kernel options are all automatic (an explicit kernel / fuse / tile choice is honoured as given).
+bool small_grid(const sfl_context *c)
+{
+    return c->opt_small_grid && c->nranks == 1 && !c->group &&
+           sfl::small_grid_fits(c->dim_x, c->gdim_y) && c->opt_sor_kernel == 0 &&
+           c->opt_sor_fuse == 0 && c->opt_sor_rows == 0 && c->opt_sor_lane_cells == 0 && c->opt_advect_kernel == 0;
+}
+
 
 int effective_halo(const sfl_context *c, int fuse)
 {
@@ -544,6 +554,13 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
     const sfl::SorParams prm = sor_params(dx, omega);
+    if (small_grid(ctx)) {  // one workgroup, p and d in LDS, every iteration in one launch
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(sfl::launch_small_solve(ctx->stream, ctx->p, ctx->div, ctx->dim_x, ctx->gdim_y, iters, prm));
+        ctx->last_launches = 1;
+        ctx->last_fuse = 2 * iters;
+        return SFL_OK;
+    }
     if (iters == 0) {  // the reference still zero-fills p (poisson.cpp:117-119)
         for (sfl_context *c : peers) {
             SFL_TRY(use_device(c));
@@ -856,6 +873,9 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_FUSE_DIVERGENCE:
             c->opt_fuse_divergence = value ? 1 : 0;
             return SFL_OK;
+        case SFL_OPT_SMALL_GRID:
+            c->opt_small_grid = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_ADVECT_KERNEL:
             if (value < 0 || value > 2) return fail(SFL_ERR_INVALID, "advection kernel must be 0, 1 or 2");
             c->opt_advect_kernel = value;
@@ -900,6 +920,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_OVERLAP: *value = c->opt_sor_overlap; return SFL_OK;
         case SFL_OPT_ADVECT_KERNEL: *value = c->opt_advect_kernel; return SFL_OK;
         case SFL_OPT_FUSE_DIVERGENCE: *value = c->opt_fuse_divergence; return SFL_OK;
+        case SFL_OPT_SMALL_GRID: *value = c->opt_small_grid; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -976,6 +997,7 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_sor_overlap = z->opt_sor_overlap;
         c->opt_advect_kernel = z->opt_advect_kernel;
         c->opt_fuse_divergence = z->opt_fuse_divergence;
+        c->opt_small_grid = z->opt_small_grid;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
@@ -1248,9 +1270,12 @@ int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy,
     return SFL_OK;
 }
 
-static int apply_queued_forces(sfl_context *c)
+// Copies the queued (cell, velocity) pairs to the device (asynchronously, through pinned staging) and empties the
+// queue; *count = how many now wait in d_force_cells / d_force_vel for the kernel that applies them.
+static int stage_queued_forces(sfl_context *c, int *count)
 {
     const int n = (int)(c->force_cells.size() / 2);
+    *count = n;
     if (n == 0) return SFL_OK;
     SFL_TRY(use_device(c));
     if (n > c->d_force_cap) {
@@ -1300,10 +1325,19 @@ static int apply_queued_forces(sfl_context *c)
                            c->stream));
     HIP_TRY(hipEventRecord(st.copied, c->stream));
     st.pending = true;
-    HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
-                                     c->d_force_vel, n));
     return SFL_OK;
 }
+
+static int apply_queued_forces(sfl_context *c)
+{
+    int n = 0;
+    SFL_TRY(stage_queued_forces(c, &n));
+    if (n > 0)
+        HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
+                                         c->d_force_vel, n));
+    return SFL_OK;
+}
+
 
 // ino:276 + ino:281-287 in one pass: project each cell's own velocity, advect the dye with it.
 static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
@@ -1351,9 +1385,46 @@ static int advect_velocity_and_divergence(sfl_context *c, float dt, float dx)
     return SFL_OK;
 }
 
+static int small_grid_step(sfl_context *c, float dt, float dx, int iters, float omega)
+{
+    if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
+    SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+    SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+    SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+    SFL_TRY(use_device(c));
+    int n_forces = 0;
+    SFL_TRY(stage_queued_forces(c, &n_forces));
+    sfl::SmallStep a{};
+    a.v_in = c->vel;
+    a.v_out = c->vel_tmp;
+    a.col_in = c->col;
+    a.col_out = c->col_tmp;
+    a.div = c->div;
+    a.p = c->p;
+    a.dim_x = c->dim_x;
+    a.dim_y = c->gdim_y;
+    a.iters = iters;
+    a.dt = dt;
+    a.two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36, :78-79
+    a.prm = sor_params(dx, omega);
+    a.force_cells = c->d_force_cells;
+    a.force_vel = c->d_force_vel;
+    a.n_forces = n_forces;
+    HIP_TRY(sfl::launch_small_step(c->stream, a));
+    std::swap(c->vel, c->vel_tmp);  // ino:255
+    std::swap(c->col, c->col_tmp);  // ino:286
+    c->last_launches = 1;
+    c->last_exchanges = 0;
+    c->last_fuse = 2 * iters;
+    return SFL_OK;
+}
+
 int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (small_grid(ctx)) return small_grid_step(ctx, dt, dx, iters, omega);
     if (can_fuse_divergence(ctx)) {
         SFL_TRY(advect_velocity_and_divergence(ctx, dt, dx));  // ino:252-256 + ino:274
     } else {

@@ -92,6 +92,11 @@ extern "C" {
                                      queued forces and advection kernel 2, the velocity advection
                                      and calculate_divergence run as one kernel (the advected tile
                                      is differenced in LDS); 0 = two kernels                       */
+#define SFL_OPT_SMALL_GRID 11      /* 1 (default) = on a whole-domain context of at most 6144 cells
+                                     whose kernel options are all automatic, sfl_poisson_solve and
+                                     sfl_step run as ONE launch of one workgroup with the fields in
+                                     LDS (the sketch's 61 x 81 grid: one launch instead of six to
+                                     ten); 0 = the general kernels                                 */
 
 typedef struct sfl_context sfl_context;
 

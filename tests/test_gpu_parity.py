@@ -906,3 +906,75 @@ def test_every_fuse_depth_from_zero_and_continuing(sfl, oracle, fuse):
             got = s.download(sfl.capi.FIELD_PRESSURE)
         assert info["fuse"] == fuse and info["launches"] == 3
         assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"fuse {fuse} dx {dx}")
+
+
+SMALL_SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (80, 60), (64, 48), (127, 33), (128, 48), (78, 78),
+                (3, 2048), (2047, 3), (2, 3072), (3072, 2), (257, 23), (128, 80), (101, 101)]
+
+
+@pytest.mark.parametrize("dim_x,dim_y", SMALL_SHAPES)
+def test_small_grid_one_launch_step_and_solve(sfl, oracle, dim_x, dim_y):
+    """SFL_OPT_SMALL_GRID (default on): grids of <= 6144 cells run sfl_poisson_solve and sfl_step as ONE launch of
+    one workgroup with the fields in LDS (the sketch's 61 x 81 among them).  Against the oracle and against the
+    general kernels: every field of the step, forces between advection and divergence, iters 0 / 1 / 9, dx != 1,
+    shapes down to 2 x 2, up to exactly 6144 cells and beyond (general kernels), including widths where one colour holds 2/3 of a row (3 x 3413: too many of one
+    colour per thread, general kernels)."""
+    v, c, d = random_fields(dim_x, dim_y, 70 + dim_x, 90.0)
+    cells = np.array([[dim_x // 2, dim_y // 2], [0, 0], [dim_x - 1, dim_y - 1], [dim_x // 2, dim_y // 2]], np.int32)
+    vel = np.array([[55.0, -35.0], [-20.0, 10.0], [3.0, 4.0], [-8.0, 6.0]], np.float32)
+    with sfl.Solver(dim_x, dim_y) as s:
+        assert s.get_option(sfl.capi.OPT_SMALL_GRID) == 1
+        for small in (1, 0):
+            s.set_option(sfl.capi.OPT_SMALL_GRID, small)
+            for iters, dx in ((9, 1.0), (1, 0.5), (0, 1.0)):
+                s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+                s.poisson_solve(dx, iters, OMEGA)
+                s.synchronize()
+                fits = dim_x * dim_y <= 6144 and dim_y * ((dim_x + 1) // 2) <= 3072   # cells of one colour per thread
+                if small and fits:
+                    assert s.last_solve_info()["launches"] == 1
+                assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, dx, iters, OMEGA),
+                                 f"solve, small {small}, iters {iters}, dx {dx}")
+                s.upload(sfl.capi.FIELD_VELOCITY, v)
+                s.upload(sfl.capi.FIELD_COLOR, c)
+                s.step(DT, dx, iters, OMEGA)
+                s.synchronize()
+                want = oracle.step(v, c, DT, dx, iters, OMEGA)
+                for field, k in ((sfl.capi.FIELD_VELOCITY, 0), (sfl.capi.FIELD_DIVERGENCE, 1),
+                                 (sfl.capi.FIELD_PRESSURE, 2), (sfl.capi.FIELD_COLOR, 3)):
+                    assert_bit_equal(s.download(field), want[k], f"step field {field}, small {small}, iters {iters}, dx {dx}")
+            # two steps, the first with drag forces between advection and divergence (last write wins)
+            s.upload(sfl.capi.FIELD_VELOCITY, v)
+            s.upload(sfl.capi.FIELD_COLOR, c)
+            s.queue_forces(cells, vel)
+            s.step(DT, 1.0, 5, OMEGA)
+            s.step(DT, 1.0, 5, OMEGA)
+            s.synchronize()
+            v1 = oracle.advect_vec2f(v, v, DT, True)
+            for (ci, cj), f in zip(cells, vel):
+                v1[cj, ci] = f
+            p1 = oracle.poisson_solve(oracle.divergence(v1, 1.0), 1.0, 5, OMEGA)
+            v1 = oracle.subtract_gradient(v1, p1, 1.0)
+            c1 = oracle.advect_vec3uq32(c, v1, DT, False)
+            want = oracle.step(v1, c1, DT, 1.0, 5, OMEGA)
+            assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), want[0], f"forced + plain step: velocity, small {small}")
+            assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), want[3], f"forced + plain step: colour, small {small}")
+
+
+def test_small_grid_limit_and_explicit_options(sfl, oracle):
+    """6145 cells take the general kernels; so does a small grid with an explicit kernel option (honoured as given)."""
+    _, _, d = random_fields(1229, 5, 5)   # 6145 cells
+    with sfl.Solver(1229, 5) as s:
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        s.poisson_solve(1.0, 12, OMEGA)
+        s.synchronize()
+        assert s.last_solve_info()["launches"] > 1
+        assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, 12, OMEGA), "6145 cells")
+    _, _, d = random_fields(61, 81, 6)
+    with sfl.Solver(61, 81) as s:
+        s.set_option(sfl.capi.OPT_SOR_FUSE, 8)
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        s.poisson_solve(1.0, 12, OMEGA)
+        s.synchronize()
+        assert s.last_solve_info()["launches"] == 3
+        assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, 12, OMEGA), "explicit fuse")
