@@ -198,9 +198,17 @@ small_step_kernel(SmallStep a)
     }
 }
 
-hipError_t allow_lds(const void *kernel, size_t bytes)
+// more than 64 KB of dynamic LDS has to be granted once per kernel and device
+hipError_t allow_lds(const void *kernel, bool *granted)
 {
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (granted[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallGridMaxCells * 16);
+    if (e == hipSuccess) granted[dev] = true;
+    return e;
 }
 
 }  // namespace
@@ -212,8 +220,9 @@ bool small_grid_fits(int dim_x, int dim_y)
 
 hipError_t launch_small_solve(hipStream_t s, float *p, const float *d, int dim_x, int dim_y, int iters, SorParams prm)
 {
+    static bool granted[64];
     const size_t lds = (size_t)dim_x * dim_y * 16;
-    hipError_t e = allow_lds(reinterpret_cast<const void *>(small_solve_kernel), lds);
+    hipError_t e = allow_lds(reinterpret_cast<const void *>(small_solve_kernel), granted);
     if (e != hipSuccess) return e;
     small_solve_kernel<<<1, kThreads, lds, s>>>(p, d, dim_x, dim_y, iters, prm);
     return hipGetLastError();
@@ -221,8 +230,9 @@ hipError_t launch_small_solve(hipStream_t s, float *p, const float *d, int dim_x
 
 hipError_t launch_small_step(hipStream_t s, const SmallStep &a)
 {
+    static bool granted[64];
     const size_t lds = (size_t)a.dim_x * a.dim_y * 16;
-    hipError_t e = allow_lds(reinterpret_cast<const void *>(small_step_kernel), lds);
+    hipError_t e = allow_lds(reinterpret_cast<const void *>(small_step_kernel), granted);
     if (e != hipSuccess) return e;
     small_step_kernel<<<1, kThreads, lds, s>>>(a);
     return hipGetLastError();
