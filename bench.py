@@ -466,10 +466,11 @@ def run_rank(args):
         algorithmic_gbs = bytes_per_launch / avg_launch_s / 1e9
         name, cus, mem = sfl.device_info(local_rank)
         pmc = pmc_record((size, dim_y), info["fuse"], world)
-        # What binds the temporally blocked kernel is the pass over memory (every
-        # depth NS <= 12 takes the same ~180 us per launch at 8192^2): `achieved` = HBM bytes the
-        # launch really moves / its duration, the bytes from the committed rocprofv3 PMC passes when
-        # one matches this configuration, else the compulsory 12 B per cell (p in, rhs in, p out).
+        # The contract names HBM or MFMA as the bound; for this stencil it is HBM (DESIGN.md 4.1 has the
+        # finer picture: a launch lasts as long as one wave's chain of iterations, ~0.87 of the access
+        # pattern's memory floor).  `achieved` = HBM bytes the launch really moves / its duration, the
+        # bytes from the committed rocprofv3 PMC passes when one matches this configuration, else the
+        # compulsory 12 B per cell (p in, rhs in, p out).
         traffic = pmc["traffic_bytes_per_launch"] if pmc else None
         compulsory = 12.0 * cells / world
         moved = traffic if traffic else compulsory
