@@ -18,7 +18,7 @@ _F = C.POINTER(C.c_float)
 @pytest.fixture(scope="module")
 def emu():
     d = os.path.join(ROOT, "tests", "cpp")
-    so = os.path.join(d, "libsor_stream_emu.so")
+    so = os.environ.get("SFL_EMU_LIB") or os.path.join(d, "libsor_stream_emu.so")
     if not os.path.exists(so):
         subprocess.run(["make", "-C", d, "-j4"], check=True, stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
