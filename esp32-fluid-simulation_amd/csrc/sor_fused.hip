@@ -12,6 +12,10 @@
 #include "kernels.h"
 #include "sor_stream_core.h"
 
+#ifndef SFL_DX_PART
+#define SFL_DX_PART (-1)  // both halves in this translation unit
+#endif
+
 namespace sfl {
 namespace {
 
@@ -356,9 +360,16 @@ template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                      SorRows rows, SorParams prm, int rows_per_chunk)
 {
+    // (a translation unit may hold only the dx == 1 kernels or only the general ones: SFL_DX_PART)
+#if SFL_DX_PART != 1
     if (prm.dx == 1.0f)
         return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
-    return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+#endif
+#if SFL_DX_PART != 0
+    if (prm.dx != 1.0f)
+        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+#endif
+    return hipErrorInvalidValue;
 }
 
 template <int NS, bool ZERO_IN>
@@ -388,22 +399,29 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 
 }  // namespace
 
-// One non-template entry per fuse depth; the depths are spread over several translation units
-// (SFL_NS_GROUP = 0..5, see csrc/Makefile) so that they compile in parallel.
+// One non-template entry per fuse depth and per half (dx == 1 / any dx); the depths and halves are spread over
+// translation units (SFL_NS_GROUP = 0..5, SFL_DX_PART = 0 / 1, see csrc/Makefile) so that they compile in parallel.
 #ifndef SFL_NS_GROUP
-#define SFL_NS_GROUP (-1)  // single translation unit: everything
+#define SFL_NS_GROUP (-1)  // single translation unit: every depth
 #endif
-#define SFL_DEFINE_NS(N)                                                                          \
-    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
-                                      Slab g, SorRows rows, SorParams prm,                        \
-                                      int rows_per_chunk, int lane_cells)                         \
+#define SFL_ENTRY_ARGS                                                                             \
+    hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, SorParams prm, \
+        int rows_per_chunk, int lane_cells
+#define SFL_DEFINE_PART(N, P)                                                                      \
+    hipError_t launch_sor_fused_ns##N##_p##P(SFL_ENTRY_ARGS)                                       \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells); \
+        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);         \
     }
+#if SFL_DX_PART == 0
+#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0)
+#elif SFL_DX_PART == 1
+#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 1)
+#else
+#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0) SFL_DEFINE_PART(N, 1)
+#endif
 #define SFL_DECLARE_NS(N)                                                                         \
-    hipError_t launch_sor_fused_ns##N(hipStream_t s, float *p_out, const float *p_in, const float *d, \
-                                      Slab g, SorRows rows, SorParams prm,                        \
-                                      int rows_per_chunk, int lane_cells);
+    hipError_t launch_sor_fused_ns##N##_p0(SFL_ENTRY_ARGS);                                       \
+    hipError_t launch_sor_fused_ns##N##_p1(SFL_ENTRY_ARGS);
 SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
 SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
@@ -425,7 +443,7 @@ SFL_DEFINE_NS(14)
 SFL_DEFINE_NS(16)
 #endif
 
-#if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
+#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int lane_cells)
@@ -435,8 +453,11 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
         p_out == p_in || p_out == nullptr || d == nullptr ||
         (lane_cells != 0 && lane_cells != 2))
         return hipErrorInvalidValue;
-#define SFL_CASE(N) \
-    case N: return launch_sor_fused_ns##N(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
+    const bool dx1 = prm.dx == 1.0f;
+#define SFL_CASE(N)                                                                                              \
+    case N:                                                                                                      \
+        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells)    \
+                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }
