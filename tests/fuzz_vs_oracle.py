@@ -10,10 +10,15 @@ capi, orc = sfl.capi, loader.port()
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # grids of 700 .. 3000 cells per side (many tiles per launch)
 t0, cases, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     kind = rng.integers(0, 4)
-    if kind == 0:
+    if big:
+        dim_x, dim_y = int(rng.integers(700, 3000)), int(rng.integers(700, 3000))
+        if rng.integers(0, 3) == 0:
+            dim_x = int(rng.choice([1024, 2048, 1536, 2560]))
+    elif kind == 0:
         dim_x, dim_y = int(rng.integers(2, 90)), int(rng.integers(2, 90))
     elif kind == 1:
         dim_x, dim_y = int(rng.integers(2, 700)), int(rng.integers(2, 700))
@@ -21,7 +26,7 @@ while time.time() - t0 < budget:
         dim_x, dim_y = int(rng.choice([64, 128, 192, 256, 320, 1024])), int(rng.integers(2, 400))
     else:
         dim_x, dim_y = int(rng.integers(2, 12)), int(rng.integers(200, 3000))
-    iters = int(rng.integers(0, 26))
+    iters = int(rng.integers(0, 26)) if not big else int(rng.integers(1, 20))
     dx = float(rng.choice([1.0, 1.0, 0.5, 1.37]))
     omega = np.float32(rng.choice([1.96, 1.0, 1.5]))
     dt = np.float32(rng.choice([1 / 30.0, 0.1, 0.004]))
