@@ -216,6 +216,49 @@ __global__ void k_relax_bpermute(float *o, float s, long long *cyc)
     stamp(cyc, t0);
 }
 
+// LDS-crossbar throughput: 16 independent ds_bpermute_b32 per iteration, one wait at the end of the block
+__global__ void k_bpermute_rate(float *o, float s, long long *cyc)
+{
+    const long long t0 = clock64();
+    float a = threadIdx.x, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    const int addr = ((threadIdx.x + 1) & 63) * 4;
+    for (int i = 0; i < ITER; ++i)
+        asm volatile(
+            "ds_bpermute_b32 %0, %5, %4\n ds_bpermute_b32 %1, %5, %4\n ds_bpermute_b32 %2, %5, %4\n ds_bpermute_b32 %3, %5, %4\n"
+            "ds_bpermute_b32 %0, %5, %4\n ds_bpermute_b32 %1, %5, %4\n ds_bpermute_b32 %2, %5, %4\n ds_bpermute_b32 %3, %5, %4\n"
+            "ds_bpermute_b32 %0, %5, %4\n ds_bpermute_b32 %1, %5, %4\n ds_bpermute_b32 %2, %5, %4\n ds_bpermute_b32 %3, %5, %4\n"
+            "ds_bpermute_b32 %0, %5, %4\n ds_bpermute_b32 %1, %5, %4\n ds_bpermute_b32 %2, %5, %4\n ds_bpermute_b32 %3, %5, %4\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(addr) : "memory");
+    o[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3;
+    stamp(cyc, t0);
+}
+// the same with ds_read2st64_b32 (what the rhs ring issues)
+__global__ void k_read2_rate(float *o, float s, long long *cyc)
+{
+    __shared__ float lds[4096];
+    const long long t0 = clock64();
+    for (int k = threadIdx.x; k < 4096; k += blockDim.x) lds[k] = k;
+    __syncthreads();
+    float r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+    const int addr = (threadIdx.x & 63) * 4;
+    for (int i = 0; i < ITER; ++i)
+        asm volatile(
+            "ds_read2st64_b32 v[10:11], %8 offset0:1 offset1:2\n ds_read2st64_b32 v[12:13], %8 offset0:3 offset1:4\n"
+            "ds_read2st64_b32 v[14:15], %8 offset0:5 offset1:6\n ds_read2st64_b32 v[16:17], %8 offset0:7 offset1:8\n"
+            "ds_read2st64_b32 v[10:11], %8 offset0:1 offset1:2\n ds_read2st64_b32 v[12:13], %8 offset0:3 offset1:4\n"
+            "ds_read2st64_b32 v[14:15], %8 offset0:5 offset1:6\n ds_read2st64_b32 v[16:17], %8 offset0:7 offset1:8\n"
+            "ds_read2st64_b32 v[10:11], %8 offset0:1 offset1:2\n ds_read2st64_b32 v[12:13], %8 offset0:3 offset1:4\n"
+            "ds_read2st64_b32 v[14:15], %8 offset0:5 offset1:6\n ds_read2st64_b32 v[16:17], %8 offset0:7 offset1:8\n"
+            "ds_read2st64_b32 v[10:11], %8 offset0:1 offset1:2\n ds_read2st64_b32 v[12:13], %8 offset0:3 offset1:4\n"
+            "ds_read2st64_b32 v[14:15], %8 offset0:5 offset1:6\n ds_read2st64_b32 v[16:17], %8 offset0:7 offset1:8\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(addr)
+            : "memory", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17");
+    o[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + lds[threadIdx.x & 1023];
+    stamp(cyc, t0);
+}
+
 template <class K>
 void run(const char *name, K k, int waves_per_simd, int insts_per_iter, float *o, long long *cyc)
 {
@@ -225,6 +268,15 @@ void run(const char *name, K k, int waves_per_simd, int insts_per_iter, float *o
     const int blocks = cus;
     for (int rep = 0; rep < 3; ++rep) k<<<blocks, threads>>>(o, 1.0f, cyc);
     hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<<<blocks, threads>>>(o, 1.0f, cyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
     const int waves = blocks * threads / 64;
     std::vector<long long> h(waves);
     hipMemcpy(h.data(), cyc, waves * sizeof(long long), hipMemcpyDeviceToHost);
@@ -232,8 +284,9 @@ void run(const char *name, K k, int waves_per_simd, int insts_per_iter, float *o
     for (long long v : h) mean += (double)v;
     mean /= waves;
     const double per_inst_wave = mean / ((double)ITER * insts_per_iter);
-    printf("%-22s %d wave(s)/SIMD: %6.2f clock64 ticks per instruction of a wave, %6.2f per instruction issued on the SIMD\n", name,
-           waves_per_simd, per_inst_wave, per_inst_wave / waves_per_simd);
+    printf("%-22s %d wave(s)/SIMD: %6.2f clock64 ticks per instruction of a wave, %6.2f per instruction issued on the SIMD   (kernel %.1f us, %.0f ticks per us, %.3f ns per instruction issued on the SIMD)\n", name,
+           waves_per_simd, per_inst_wave, per_inst_wave / waves_per_simd, ms * 1e3, mean / (ms * 1e3),
+           ms * 1e6 / ((double)ITER * insts_per_iter * waves_per_simd));
 }
 
 int main()
@@ -254,7 +307,9 @@ int main()
         run("dpp in every 2nd relax", k_relax_half, w, 128, o, cyc);
         run("dpp in every 4th relax", k_relax_quarter, w, 128, o, cyc);
         run("two chains, dpp in one", k_relax_two_chains, w, 256, o, cyc);
-        run("relaxation, ds_bpermute", k_relax_bpermute, w, 16 * 8, o, cyc);   // per 8 "useful" instructions: compare with the chains
+        run("relaxation, ds_bpermute", k_relax_bpermute, w, 16 * 8, o, cyc);
+        run("ds_bpermute_b32 alone", k_bpermute_rate, w, 16, o, cyc);
+        run("ds_read2st64_b32 alone", k_read2_rate, w, 16, o, cyc);   // per 8 "useful" instructions: compare with the chains
     }
     return 0;
 }
