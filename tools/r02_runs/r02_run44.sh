@@ -2,7 +2,7 @@
 # diagnostic builds of the NS = 16 / dx = 1 kernels: without global memory traffic, without LDS traffic (results wrong by design)
 set -u
 export TMPDIR=/tmp
-for v in base diag1 diag2 base diag1 diag2; do
+for v in base diag3 diag4 diag5 base diag3 diag4 diag5; do
   L=""; [ $v != base ] && L=$PWD/esp32-fluid-simulation_amd/lib/variants/libsfl_hip_$v.so
   SFL_LIB=$L python bench.py --no-cpu-baseline --sim-steps 0 --steps 30 --warmup 5 > gpurun_out/r02_run44.json 2>/dev/null
   python - <<PY
