@@ -507,7 +507,10 @@ def run_rank(args):
                                         f"{VALU_CLOCK_GHZ} GHz = half of the 157.3 TFLOP/s fp32 vector peak (no "
                                         "FMA: the reference rounds every product and sum)",
                      "issued_over_useful": (pmc["valu_wave_insts_per_launch"] / useful_insts)
-                     if pmc and pmc.get("valu_wave_insts_per_launch") else None},
+                     if pmc and pmc.get("valu_wave_insts_per_launch") else None,
+                     "note": "the shader clock under this kernel is ~1.2 GHz (power), measured with clock64() "
+                             "inside the kernel (profiles/r02_rhs_read_ahead.txt): at that clock the SIMDs issue "
+                             "throughout; the peak above is the nominal 2.4 GHz"},
         }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",
