@@ -29,20 +29,63 @@ inline int flip_tiles()
 }
 constexpr int kThreads = 64 * kWavesPerBlock;
 
+#ifdef SFL_SOR_TRACE
+// Diagnostic builds only (tools/sor_clock_probe.hip; never defined for the product library): every wave
+// records when it started and ended on the shader clock (s_memtime) AND on the constant 100 MHz
+// real-time clock (s_memrealtime), plus where it ran -- 6 words per tile.
+__device__ unsigned long long *g_sor_trace;
+struct WaveTrace {
+    unsigned long long t0, w0;
+    unsigned hwid, xcc;
+    __device__ __forceinline__ void begin()
+    {
+        t0 = __builtin_readcyclecounter();
+        w0 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    }
+    __device__ __forceinline__ void end(int tile, int kind) const
+    {
+        const unsigned long long t1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && g_sor_trace) {
+            unsigned long long *o = g_sor_trace + 6 * (size_t)tile;
+            o[0] = t0; o[1] = t1; o[2] = w0; o[3] = w1; o[4] = hwid; o[5] = ((unsigned long long)kind << 32) | xcc;
+        }
+    }
+};
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 // DPP full-wave shifts (GFX9 wave_shr:1 / wave_shl:1).  Lane 0 / lane 63 receive 0, which only
 // ever feeds cells of the tile's invalid rim.
+#ifndef SFL_PRIO_LEVELS
+#define SFL_PRIO_LEVELS 4  // priority levels the waves of a SIMD rotate through (1 = leave the priority alone)
+#endif
+#ifndef SFL_PRIO_ROWS
+#define SFL_PRIO_ROWS 6    // rows (pipeline iterations) a wave spends on one level; must divide 6
+#endif
+#ifndef SFL_PROBE_NO_LDS
+#define SFL_PROBE_NO_LDS 0   // diagnostic builds only: no rhs ring traffic (wrong results)
+#endif
+#ifndef SFL_PROBE_NO_LOAD
+#define SFL_PROBE_NO_LOAD 0  // diagnostic builds only: no global loads (wrong results)
+#endif
+#ifndef SFL_PROBE_SHIFT
+#define SFL_PROBE_SHIFT 0  // diagnostic builds only (tools/sor_clock_probe.hip): 1 = no lane shift at all, 2 = row_shr / row_shl
+#endif
 __device__ __forceinline__ float lane_below(float x)  // value of lane - 1
 {
+    if (SFL_PROBE_SHIFT == 1) return x;
     return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), SFL_PROBE_SHIFT == 2 ? 0x111 : 0x138, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float lane_above(float x)  // value of lane + 1
 {
+    if (SFL_PROBE_SHIFT == 1) return x;
     return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), SFL_PROBE_SHIFT == 2 ? 0x101 : 0x130, 0xf, 0xf, false));
 }
 
 // State shared by both flavours.  Loads are UNCONDITIONAL and branch-free: the row index is
@@ -59,6 +102,7 @@ struct WaveCommon {
     int grow0;           // global row of local row 0
     int row_lo, row_hi;  // global rows present in the local arrays AND inside the domain
     int row_sign;        // +1: pipeline row index = domain row; -1: its negative (tile streamed top-down)
+    int prio_turn;       // rotating issue priority: this wave's turn counter (see next_trip)
 
     // the pipeline speaks in row INDICES t; domain row = row_sign * t (same parity either way)
     __device__ __forceinline__ sor::RowFacts row_facts(int t) const
@@ -68,6 +112,49 @@ struct WaveCommon {
     }
     template <class P>
     __device__ __forceinline__ void poison(P &) const {}
+
+    // Rotating issue priority.  The SIMD's arbiter serves the waves it holds by priority, then AGE: with
+    // equal priorities the oldest wave issues whenever it can (one dependent VALU instruction per ~4.3
+    // cycles, 2 of them busy), the second fills the gaps and the third starves -- measured with
+    // tools/sor_clock_probe.hip at 8192^2, NS = 16: the three waves of a SIMD finish after 228 k, 262 k and
+    // 362 k cycles, the last one running alone (35 % VALU use) for the final quarter of the launch.  Every
+    // wave therefore moves to the next priority level at each trip (its start level comes from its hardware
+    // wave slot, so the waves of a SIMD start on different levels): over its life each wave spends the same
+    // share of trips at each level, all advance at the same pace and the SIMD stays full to the end.
+    __device__ __forceinline__ void start_turns()
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));  // wave slot on the SIMD
+        prio_turn = (int)(hw % SFL_PRIO_LEVELS);
+    }
+    __device__ __forceinline__ void next_turn()
+    {
+        if (SFL_PRIO_LEVELS <= 1) return;
+        prio_turn = prio_turn + 1 >= SFL_PRIO_LEVELS ? prio_turn + 1 - SFL_PRIO_LEVELS : prio_turn + 1;
+        // s_setprio takes an immediate: select it with scalar branches INSIDE one asm statement, so that the
+        // straight-line trip stays straight-line for the compiler (a visible branch makes its wait-count pass
+        // drain the loads in flight)
+        asm volatile("s_cmp_lg_u32 %0, 0\n\t"
+                     "s_cbranch_scc1 .Lsfl_p1_%=\n\t"
+                     "s_setprio 0\n\t"
+                     "s_branch .Lsfl_pe_%=\n"
+                     ".Lsfl_p1_%=:\n\t"
+                     "s_cmp_lg_u32 %0, 1\n\t"
+                     "s_cbranch_scc1 .Lsfl_p2_%=\n\t"
+                     "s_setprio 1\n\t"
+                     "s_branch .Lsfl_pe_%=\n"
+                     ".Lsfl_p2_%=:\n\t"
+                     "s_cmp_lg_u32 %0, 2\n\t"
+                     "s_cbranch_scc1 .Lsfl_p3_%=\n\t"
+                     "s_setprio 2\n\t"
+                     "s_branch .Lsfl_pe_%=\n"
+                     ".Lsfl_p3_%=:\n\t"
+                     "s_setprio 3\n"
+                     ".Lsfl_pe_%=:"
+                     :
+                     : "s"(prio_turn)
+                     : "scc");
+    }
     __device__ __forceinline__ int row_bytes(int t) const { return (row_sign * t - grow0) * dim_x * 4; }
     __device__ __forceinline__ int load_row_bytes(int t) const
     {
@@ -88,7 +175,7 @@ struct Lane2 : WaveCommon {
     using M = bool;
         // three rows in flight ahead of the pipeline: six cost 12 more VGPRs (and, with the rhs read-ahead, spills
     // at NS = 16) without being faster (profiles/r02_rhs_read_ahead.txt)
-    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 3;
+    static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 3, kTurnRows = SFL_PRIO_ROWS;
     // LDS per wave: the rhs ring (RING rows x 2 planes x 64 lanes x 4 B)
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
@@ -140,6 +227,10 @@ struct Lane2 : WaveCommon {
     }
     __device__ __forceinline__ void load_row(int r, V &pa, V &pb, V &da, V &db) const
     {
+        if (SFL_PROBE_NO_LOAD) {
+            asm volatile("" : "+v"(pa), "+v"(pb), "+v"(da), "+v"(db));
+            return;
+        }
         const int soff = load_row_bytes(r);
         if (VEC) {
             const v2f f = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_d, off_a, soff, 0));
@@ -181,18 +272,30 @@ struct Lane2 : WaveCommon {
     // every call site, so each access is one DS instruction with an immediate offset
     __device__ __forceinline__ void ring_store(int slot, int plane, V x) const
     {
+        if (SFL_PROBE_NO_LDS) return;
         ring[(slot * 2 + plane) * 64] = x;
     }
     __device__ __forceinline__ void pin() const { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ V ring_load(int slot, int plane) const
     {
+        if (SFL_PROBE_NO_LDS) {
+            V r = __builtin_bit_cast(float, off_out);
+            asm volatile("" : "+v"(r));
+            return r;
+        }
         return ring[(slot * 2 + plane) * 64];
     }
 };
 
 // Occupancy the register allocator must keep: a launch lasts as long as one wave's chain of iterations, and
 // that chain is served best with >= 3 waves on the SIMD (NS >= 12: 168 VGPRs) / 4 (NS <= 10: 128).
-constexpr int min_waves_per_simd(int ns) { return ns >= 12 ? 3 : 4; }
+#ifndef SFL_MIN_WAVES_DEEP
+#define SFL_MIN_WAVES_DEEP 3
+#endif
+#ifndef SFL_PROBE_NO_EDGE
+#define SFL_PROBE_NO_EDGE 0  // diagnostic builds only: every tile takes the interior path (wrong results at the walls)
+#endif
+constexpr int min_waves_per_simd(int ns) { return ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
@@ -219,6 +322,12 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // the tiles of the second tiling follow those of the first
     int tile = block * kWavesPerBlock + wave;
     if (tile >= t1.n_tiles + t2.n_tiles) return;
+#ifdef SFL_SOR_TRACE
+    WaveTrace trace;
+    trace.begin();
+    const int trace_tile = tile;
+    int trace_kind = 0;
+#endif
     const bool second = tile >= t1.n_tiles;  // wave-uniform
     const sor::Tiling t = second ? t2 : t1;
     if (second) tile -= t1.n_tiles;
@@ -243,27 +352,38 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.row_lo = max(g.grow0, 0);
         bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
         bk.row_sign = 1;
+        bk.start_turns();
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
         return bk;
     };
-    if (sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
+    if (!SFL_PROBE_NO_EDGE && sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
         B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
+#ifdef SFL_SOR_TRACE
+        trace_kind = 1;
+#endif
     } else if (sor::tile_may_flip(t, rect)) {  // streamed top-down: pipeline index = -row
         B bk = backend();
         bk.row_sign = -1;
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN, true>(bk, c, none, none, 1 - r1, 1 - r0);
+#ifdef SFL_SOR_TRACE
+        trace_kind = 2;
+#endif
     } else {
         B bk = backend();
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
     }
+#ifdef SFL_SOR_TRACE
+    __builtin_amdgcn_s_waitcnt(0);  // the wave's stores have left
+    trace.end(trace_tile, trace_kind);
+#endif
 }
 
 // Resident waves of one instantiation on the whole device (occupancy query, cached).

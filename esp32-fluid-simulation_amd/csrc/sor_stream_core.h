@@ -156,6 +156,9 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
     constexpr int kPrefetch = B::kPrefetch;
     constexpr int Q = U % kPrefetch;
 
+    // the waves that share a SIMD take turns at the top issue priority (Lane2::next_turn; a no-op in the emulator)
+    if (U % B::kTurnRows == 0) bk.next_turn();
+
     // ---- row y enters: hand it to version 0, park its d in the ring, refill the slot ----
     {
         // detach(): an explicit register copy, so that the prefetch registers are free to
@@ -295,7 +298,7 @@ SFL_HD void stream_tile(B &bk, const Consts<B> &c, const EdgeCell<B> &eca,
         run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 0, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
         y += RING;
         if (prologue_trips(NS) >= 2 && y + RING <= y_stop) {
-            run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
+                run_unrolled<B, NS, EDGE, DX1, ZERO_IN, 1, false, FLIP>(bk, pp, c, eca, ecb, y, out_begin, out_end, us);
             y += RING;
         }
     }

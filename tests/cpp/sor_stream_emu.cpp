@@ -156,6 +156,8 @@ struct EmuBackend {
     }
     V detach(const V &x) const { return x; }
     void pin() const {}
+    static constexpr int kTurnRows = 6;
+    void next_turn() {}
 };
 
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
