@@ -221,6 +221,13 @@ def parse_args(argv=None):
                     help="advection kernels: 0 auto, 1 one thread per cell, 2 LDS-staged tiles (A/B)")
     ap.add_argument("--no-fuse-projection", action="store_true",
                     help="sim step: separate subtract_gradient and dye-advection kernels (A/B)")
+    ap.add_argument("--emulate-rank", type=int, default=-1,
+                    help="with --of N: run rank R's program of an N-GPU solve ALONE on one GPU, every halo message "
+                         "replaced by a self-copy of the same size on the exchange stream (sfl_comm_emulate); reports "
+                         "ms per solve of that rank = the per-GPU critical path without the wire; results next to "
+                         "the cuts are meaningless, so parity and the CPU baseline are skipped")
+    ap.add_argument("--of", type=int, default=8, help="group size for --emulate-rank")
+    ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous plumbing only: the ranks touch no GPU (CPU test)")
     return ap.parse_args(argv)
@@ -303,7 +310,18 @@ def run_rank(args):
 
     size, iters = args.size, args.iters
     dim_y = args.dim_y or size
-    s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
+    emulate = args.emulate_rank >= 0
+    if emulate:
+        if world != 1:
+            sys.exit("--emulate-rank runs on ONE GPU")
+        s = sfl.Solver(size, dim_y, device=local_rank, rank=args.emulate_rank, nranks=args.of)
+        s.comm_emulate()
+        args.no_cpu_baseline = True
+        args.sim_steps = 0
+    else:
+        s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
+    if args.no_overlap:
+        s.set_option(capi.OPT_SOR_OVERLAP, 0)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
                      (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
                      (capi.OPT_SOR_HALO, args.sor_halo), (capi.OPT_ADVECT_KERNEL, args.advect_kernel)):
@@ -332,6 +350,8 @@ def run_rank(args):
 
     omega = np.float32(1.96)
     cells = size * dim_y
+    if emulate:
+        cells = size * (s.row_end - s.row_begin)   # what this rank relaxes per iteration
 
     def timed_region():
         """W untimed + K timed solves, barrier + device sync on both sides, max over ranks."""
@@ -457,6 +477,22 @@ def run_rank(args):
                   "tolerance": "1e-5 relative allowed by north_star; asserted 0 ulp"}
 
     rc = 0
+    if emulate:
+        name, cus, mem = sfl.device_info(local_rank)
+        print(json.dumps({
+            "emulated_rank": args.emulate_rank, "of": args.of, "grid": [size, dim_y], "iters": iters,
+            "rows_owned": s.row_end - s.row_begin, "ms_per_solve": elapsed / args.steps * 1e3,
+            "ms_per_solve_hip_events": ev_ms / args.steps, "ms_per_solve_unprimed":
+            (cells * iters / unprimed * 1e3) if unprimed else None,
+            "cell_iters_per_sec_of_this_rank": cells * iters * args.steps / elapsed,
+            "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
+            "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
+            "note": "one rank's program alone on one GPU, halo messages as self-copies of the same size on the "
+                    "exchange stream (sfl_comm_emulate); values next to the cuts are meaningless",
+            "device": name}), flush=True)
+        s.close()
+        rdzv.close()
+        return 0
     if rank == 0:
         value = cells * iters * args.steps / elapsed
         launches = max(info["launches"], 1)

@@ -94,8 +94,10 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 // p is then implicitly zero, the fused zero-fill of poisson.cpp:117-119) and d, writes the
 // result for the global rows of `rows` to p_out (p_out must not alias p_in).  Needs p_in
 // valid on rows [g_begin - nsweeps, g_end + nsweeps) and d on one row less each side, clipped
-// to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).  lane_cells =
-// cells per lane: 2, or 0 (auto = 2); kept as a parameter for the option it serves.
+// to the domain.  rows_per_chunk = output rows streamed by one wave (0 = auto).  sweep = index of
+// the launch within its solve: odd launches stream every tile in the direction opposite to the even
+// ones, so that a launch begins on the rows the previous one touched last (still in the Infinity
+// Cache); speed only, any value gives the same bits.
 // One launch covers output rows [g_begin, g_end) and, optionally, a second disjoint range
 // [g2_begin, g2_end) (the two cut-adjacent bands of a slab around a halo exchange in ONE launch).
 #define SFL_MAX_FUSE 16
@@ -105,7 +107,7 @@ struct SorRows {
 };
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int lane_cells);
+                            SorParams prm, int rows_per_chunk, int sweep);
 
 // ---- small grids: one workgroup, fields in LDS (small_grid.hip) -------------------------------------
 // WHOLE-DOMAIN arrays of dim_x * dim_y <= kSmallGridMaxCells cells (16 B of LDS per cell: 96 KB of the CU's 160;

@@ -60,6 +60,7 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int kGhostRows = 64;  // ghost rows allocated per side on a slab (nranks > 1)
+constexpr size_t kAlternateSweepCells = 48u << 20;  // local cells from which successive SOR launches alternate direction
 
 size_t field_elem_bytes(int field)
 {
@@ -136,6 +137,7 @@ struct sfl_context {
         opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1;
 
     ncclComm_t comm = nullptr;
+    bool emulated = false;              // sfl_comm_emulate: one rank's program with self-copies as transport
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
 
@@ -280,6 +282,18 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
     }
 
     sfl_context *c = any;
+    if (c->emulated) {
+        // ONE rank of the group runs alone (bench.py --emulate-rank): every message it would send is copied,
+        // same size, same stream, into the ghost rows it would receive into.  The bytes are this rank's own,
+        // so results next to the cuts mean nothing; launches, copies and their ordering are the rank's program.
+        SFL_TRY(use_device(c));
+        hipStream_t st = on ? on : c->stream;
+        if (c->rank > 0)
+            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - rows), row_ptr(c, c->g0), bytes, hipMemcpyDeviceToDevice, st));
+        if (c->rank < c->nranks - 1)
+            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1), row_ptr(c, c->g1 - rows), bytes, hipMemcpyDeviceToDevice, st));
+        return SFL_OK;
+    }
     if (!c->comm)
         return fail(SFL_ERR_STATE, "slab %d/%d has no communicator: call sfl_comm_attach() or "
                     "sfl_group_link() first", c->rank, c->nranks);
@@ -361,9 +375,14 @@ int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParam
 {
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
     SFL_TRY(use_device(c));
+    // Slabs that outgrow the Infinity Cache (256 MB; p + d of 48 M cells = 384 MB) reverse the stream direction of
+    // every tile from one launch to the next: a launch then begins on the rows its predecessor read and wrote
+    // last, the only ones still cached (8192^2: -3 % per launch; no gain or a small loss on slabs that fit:
+    // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
+    const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
     HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div, c->geom,
                                   sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
-                                  prm, c->opt_sor_rows, c->opt_sor_lane_cells));
+                                  prm, c->opt_sor_rows, sweep));
     return SFL_OK;
 }
 
@@ -437,7 +456,7 @@ int await_exchange(const std::vector<sfl_context *> &peers, const Overlap &o)
 int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows)
 {
     if (rows <= 0 || ctx->nranks == 1) return SFL_OK;
-    if (!ctx->comm) return exchange(peers, field, rows);
+    if (!ctx->comm && !ctx->emulated) return exchange(peers, field, rows);
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
     SFL_TRY(start_exchange(peers, o, field, rows));
@@ -568,7 +587,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         }
         return SFL_OK;
     }
-    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && (ctx->comm || ctx->group))
+    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && (ctx->comm || ctx->group || ctx->emulated))
         return run_poisson_overlapped(ctx, peers, progs, prm);
     for (size_t i = 0; i < progs[0].size(); ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -913,7 +932,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_FUSE: *value = c->opt_sor_fuse; return SFL_OK;
         case SFL_OPT_ADVECT_HALO: *value = c->opt_advect_halo; return SFL_OK;
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
-        case SFL_OPT_TRANSPORT: *value = c->comm ? 1 : (c->group ? 2 : 0); return SFL_OK;
+        case SFL_OPT_TRANSPORT: *value = c->comm ? 1 : (c->group ? 2 : (c->emulated ? 3 : 0)); return SFL_OK;
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
@@ -948,11 +967,20 @@ int sfl_comm_unique_id(void *id_out, size_t id_bytes)
 int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
 {
     if (!c || !id || id_bytes < sizeof(ncclUniqueId)) return fail(SFL_ERR_INVALID, "bad arguments");
-    if (c->comm || c->group) return fail(SFL_ERR_STATE, "context already has a transport");
+    if (c->comm || c->group || c->emulated) return fail(SFL_ERR_STATE, "context already has a transport");
     SFL_TRY(use_device(c));
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     NCCL_TRY(ncclCommInitRank(&c->comm, c->nranks, uid, c->rank));
+    return SFL_OK;
+}
+
+int sfl_comm_emulate(sfl_context *c)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (c->comm || c->group) return fail(SFL_ERR_STATE, "context already has a transport");
+    if (c->nranks < 2) return fail(SFL_ERR_STATE, "a whole-domain context has nothing to exchange");
+    c->emulated = true;
     return SFL_OK;
 }
 

@@ -20,13 +20,11 @@ namespace sfl {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-constexpr size_t kNtStoreCells = 24u << 20;  // local cells from which p is stored non-temporally
+#ifndef SFL_NT_STORE_CELLS
+#define SFL_NT_STORE_CELLS (24u << 20)
+#endif
+constexpr size_t kNtStoreCells = SFL_NT_STORE_CELLS;  // local cells from which p is stored non-temporally
 constexpr int kFlipTiles = 1;                // alternate the stream direction of vertically adjacent tiles
-inline int flip_tiles()
-{
-    static const int on = [] { const char *e = getenv("SFL_SOR_FLIP"); return e ? atoi(e) : kFlipTiles; }();
-    return on;
-}
 constexpr int kThreads = 64 * kWavesPerBlock;
 
 #ifdef SFL_SOR_TRACE
@@ -64,7 +62,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define SFL_PRIO_LEVELS 4  // priority levels the waves of a SIMD rotate through (1 = leave the priority alone)
 #endif
 #ifndef SFL_PRIO_ROWS
-#define SFL_PRIO_ROWS 6    // rows (pipeline iterations) a wave spends on one level; must divide 6
+#define SFL_PRIO_ROWS 2    // rows (pipeline iterations) a wave spends on one level; must divide 6
 #endif
 #ifndef SFL_PROBE_NO_LDS
 #define SFL_PROBE_NO_LDS 0   // diagnostic builds only: no rhs ring traffic (wrong results)
@@ -454,7 +452,7 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                          SorRows rows, SorParams prm, int rows_per_chunk)
+                          SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
 {
     auto tiling = [&](int g_begin, int g_end) {
         if (g_end <= g_begin) {
@@ -466,7 +464,7 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
         if (rpc <= 0)
             rpc = auto_rows_per_chunk<B>(g, g_begin, g_end, NS, resident_waves<B, NS, DX1, ZERO_IN>(), device_simds());
         return sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin, g_end, rpc,
-                                sor::kEdgeRowCost16, flip_tiles());
+                                sor::kEdgeRowCost16, kFlipTiles ? 1 + (sweep & 1) : 0);
     };
     const sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
     const int tiles = t1.n_tiles + t2.n_tiles;
@@ -478,23 +476,23 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
 
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
 {
     // (a translation unit may hold only the dx == 1 kernels or only the general ones: SFL_DX_PART)
 #if SFL_DX_PART != 1
     if (prm.dx == 1.0f)
-        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
 #endif
 #if SFL_DX_PART != 0
     if (prm.dx != 1.0f)
-        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
 #endif
     return hipErrorInvalidValue;
 }
 
 template <int NS, bool ZERO_IN>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                       SorRows rows, SorParams prm, int rows_per_chunk, int lane_cells)
+                       SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
@@ -502,19 +500,19 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     if (can2v) {
         // non-temporal stores once the slab's arrays no longer fit the caches (see Lane2)
         if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
-            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
     }
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
 }
 
 template <int NS>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk, int lane_cells)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
 }
 
 }  // namespace
@@ -526,11 +524,11 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 #endif
 #define SFL_ENTRY_ARGS                                                                             \
     hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, SorParams prm, \
-        int rows_per_chunk, int lane_cells
+        int rows_per_chunk, int sweep
 #define SFL_DEFINE_PART(N, P)                                                                      \
     hipError_t launch_sor_fused_ns##N##_p##P(SFL_ENTRY_ARGS)                                       \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);         \
+        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);         \
     }
 #if SFL_DX_PART == 0
 #define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0)
@@ -566,18 +564,17 @@ SFL_DEFINE_NS(16)
 #if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int lane_cells)
+                            SorParams prm, int rows_per_chunk, int sweep)
 {
     if (rows.g_end <= rows.g_begin && rows.g2_end <= rows.g2_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
-        p_out == p_in || p_out == nullptr || d == nullptr ||
-        (lane_cells != 0 && lane_cells != 2))
+        p_out == p_in || p_out == nullptr || d == nullptr)
         return hipErrorInvalidValue;
     const bool dx1 = prm.dx == 1.0f;
 #define SFL_CASE(N)                                                                                              \
     case N:                                                                                                      \
-        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells)    \
-                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, lane_cells);
+        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep)    \
+                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }

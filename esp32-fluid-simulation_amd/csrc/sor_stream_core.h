@@ -339,7 +339,8 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
-    int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect)
+    int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect):
+                          // 1 = the odd chunks, 2 = the even ones, 0 = none
 };
 
 struct TileRect {
@@ -431,7 +432,7 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile)
     const int inner_tiles = t.n_inner * t.n_chunks;
     if (tile < inner_tiles) {
         const int chunk = tile / t.n_inner;
-        r.flip = t.flip && (chunk & 1);
+        r.flip = t.flip && ((chunk & 1) == (t.flip & 1));  // flip = 1: the odd chunks, 2: the even ones
         r.strip = 1 + (tile - chunk * t.n_inner);
         const int has_first = t.rows_first > 0;
         if (has_first && chunk == 0) {

@@ -119,6 +119,10 @@ class Solver:
     def comm_loopback(self, rows: int):
         capi.check(self._lib.sfl_comm_loopback(self._h, rows))
 
+    def comm_emulate(self):
+        """This rank's program alone, halo messages as self-copies (timing only; sfl_comm_emulate)."""
+        capi.check(self._lib.sfl_comm_emulate(self._h))
+
     @staticmethod
     def link_group(solvers):
         """Join slabs living on one device into an in-process group (virtual ranks)."""

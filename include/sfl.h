@@ -70,7 +70,8 @@ extern "C" {
                                      correct for any velocity                                     */
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
-                                     1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link)  */
+                                     1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link),
+                                     3 = emulated (sfl_comm_emulate: timing only)                 */
 #define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto or 2 (the only flavour
                                      left: round 1's packed 4-cell tiles were never faster)        */
 #define SFL_OPT_SOR_HALO 6        /* rows of p exchanged per superstep on a slab (kernel 2): 0 =
@@ -217,6 +218,12 @@ SFL_API int sfl_comm_attach(sfl_context *ctx, const void *id, size_t id_bytes);
  * this rank itself and receive them into the first `rows` owned rows of the pressure field --
  * the same pointer / count / stream arithmetic as a neighbour halo exchange.                  */
 SFL_API int sfl_comm_loopback(sfl_context *ctx, int rows);
+/* Measurement aid for boxes with fewer GPUs than ranks: this slab context runs ITS rank's program alone.
+ * Every halo message it would send is copied -- same size, same stream, same ordering events -- into the
+ * ghost rows it would receive into, so launches, copies and their overlap are exactly the rank's own while
+ * the values next to the cuts are meaningless (never use the results).  SFL_OPT_TRANSPORT reads 3.
+ * bench.py --emulate-rank R --of N reports the time of one solve on such a context.                 */
+SFL_API int sfl_comm_emulate(sfl_context *ctx);
 /* In-process transport between virtual ranks living on ONE device (bring-up / tests):
  * ctxs[r] must be slab r of nranks == n, all created on the same device.                   */
 SFL_API int sfl_group_link(sfl_context **ctxs, int n);

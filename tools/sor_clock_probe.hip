@@ -82,7 +82,11 @@ int main(int argc, char **argv)
     const sfl::Slab g{dim_x, dim_y, 0, dim_y};
     const sfl::SorRows rows{0, dim_y, 0, 0};
     sfl::SorParams prm{1.0f, 1.96f, 1.0f - 1.96f};
-    auto launch = [&](float *out, const float *in) { return sfl::PROBE_LAUNCH(st, out, in, d, g, rows, prm, rpc, 0); };
+    const int alternate = getenv("PROBE_ALTERNATE") ? atoi(getenv("PROBE_ALTERNATE")) : 0;
+    int n_launch = 0;
+    auto launch = [&](float *out, const float *in) {
+        return sfl::PROBE_LAUNCH(st, out, in, d, g, rows, prm, rpc, alternate ? n_launch++ : 0);
+    };
 
     if (loop_s > 0) {  // a steady load for clock polling from outside (rocm-smi / amd-smi)
         const auto t0 = std::chrono::steady_clock::now();
