@@ -242,16 +242,19 @@ int min_owned_rows(const sfl_context *c)
 // Every rank sends its `rows` lowest owned rows down and its `rows` highest owned rows up, and
 // receives the neighbours' into the ghost rows adjacent to its owned block.
 // `on` = stream to issue the transfers on (nullptr: the contexts' compute stream).
-int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipStream_t on = nullptr)
+// `skip` > 0: only the rows at depth [skip, skip + rows) from the cuts travel (the ghost rows nearer the cut
+// are still valid: early exchanges of slab_plan.cpp).
+int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipStream_t on = nullptr, int skip = 0)
 {
     if (rows <= 0) return SFL_OK;
     sfl_context *any = peers[0];
     if (any->nranks == 1) return SFL_OK;
-    if (rows > any->ghost)
-        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the %d ghost rows of a slab", rows,
+    if (skip < 0) return fail(SFL_ERR_INVALID, "negative halo offset");
+    if (skip + rows > any->ghost)
+        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the %d ghost rows of a slab", skip + rows,
                     any->ghost);
-    if (rows > min_owned_rows(any))
-        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the thinnest slab (%d rows)", rows,
+    if (skip + rows > min_owned_rows(any))
+        return fail(SFL_ERR_INVALID, "halo of %d rows exceeds the thinnest slab (%d rows)", skip + rows,
                     min_owned_rows(any));
     const size_t eb = field_elem_bytes(field);
     for (sfl_context *c : peers) {
@@ -269,12 +272,12 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
             SFL_TRY(use_device(c));
             if (c->rank > 0) {
                 sfl_context *lo = peers[c->rank - 1];
-                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - rows), row_ptr(lo, lo->g1 - rows), bytes,
+                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - skip - rows), row_ptr(lo, lo->g1 - skip - rows), bytes,
                                        hipMemcpyDeviceToDevice, on ? on : c->stream));
             }
             if (c->rank < c->nranks - 1) {
                 sfl_context *hi = peers[c->rank + 1];
-                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1), row_ptr(hi, hi->g0), bytes,
+                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1 + skip), row_ptr(hi, hi->g0 + skip), bytes,
                                        hipMemcpyDeviceToDevice, on ? on : c->stream));
             }
         }
@@ -289,9 +292,11 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         SFL_TRY(use_device(c));
         hipStream_t st = on ? on : c->stream;
         if (c->rank > 0)
-            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - rows), row_ptr(c, c->g0), bytes, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - skip - rows), row_ptr(c, c->g0 + skip), bytes,
+                                   hipMemcpyDeviceToDevice, st));
         if (c->rank < c->nranks - 1)
-            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1), row_ptr(c, c->g1 - rows), bytes, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1 + skip), row_ptr(c, c->g1 - skip - rows), bytes,
+                                   hipMemcpyDeviceToDevice, st));
         return SFL_OK;
     }
     if (!c->comm)
@@ -301,12 +306,12 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
     hipStream_t st = on ? on : c->stream;
     NCCL_TRY(ncclGroupStart());
     if (c->rank > 0) {
-        NCCL_TRY(ncclSend(row_ptr(c, c->g0), bytes, ncclChar, c->rank - 1, c->comm, st));
-        NCCL_TRY(ncclRecv(row_ptr(c, c->g0 - rows), bytes, ncclChar, c->rank - 1, c->comm, st));
+        NCCL_TRY(ncclSend(row_ptr(c, c->g0 + skip), bytes, ncclChar, c->rank - 1, c->comm, st));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g0 - skip - rows), bytes, ncclChar, c->rank - 1, c->comm, st));
     }
     if (c->rank < c->nranks - 1) {
-        NCCL_TRY(ncclSend(row_ptr(c, c->g1 - rows), bytes, ncclChar, c->rank + 1, c->comm, st));
-        NCCL_TRY(ncclRecv(row_ptr(c, c->g1), bytes, ncclChar, c->rank + 1, c->comm, st));
+        NCCL_TRY(ncclSend(row_ptr(c, c->g1 - skip - rows), bytes, ncclChar, c->rank + 1, c->comm, st));
+        NCCL_TRY(ncclRecv(row_ptr(c, c->g1 + skip), bytes, ncclChar, c->rank + 1, c->comm, st));
     }
     NCCL_TRY(ncclGroupEnd());
     return SFL_OK;
@@ -371,7 +376,7 @@ int effective_halo(const sfl_context *c, int fuse)
 // One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
 // all pieces read c->p and write c->p_alt; the caller swaps once per step).
 int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
-                    int g2_begin = 0, int g2_end = 0)
+                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr)
 {
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
     SFL_TRY(use_device(c));
@@ -380,7 +385,7 @@ int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParam
     // last, the only ones still cached (8192^2: -3 % per launch; no gain or a small loss on slabs that fit:
     // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
     const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
-    HIP_TRY(sfl::launch_sor_fused(c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div, c->geom,
+    HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div, c->geom,
                                   sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
                                   prm, c->opt_sor_rows, sweep));
     return SFL_OK;
@@ -432,12 +437,22 @@ int overlap_of(sfl_context *c, Overlap *o)
 
 // Halo exchange off the compute stream: starts once everything issued so far on the compute
 // stream has completed, runs on the exchange stream; `arrived` marks its completion.
-int start_exchange(const std::vector<sfl_context *> &peers, const Overlap &o, int field, int rows)
+// `mark` = false: the caller queues more work behind the exchange on the exchange stream and records
+// `arrived` itself (mark_arrived).
+int start_exchange(const std::vector<sfl_context *> &peers, const Overlap &o, int field, int rows, int skip = 0,
+                   bool mark = true)
 {
     SFL_TRY(use_device(peers[0]));
     HIP_TRY(hipEventRecord(o.ready, o.compute));
     HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
-    SFL_TRY(exchange(peers, field, rows, o.xstream));
+    SFL_TRY(exchange(peers, field, rows, o.xstream, skip));
+    SFL_TRY(use_device(peers[0]));
+    if (mark) HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+    return SFL_OK;
+}
+
+int mark_arrived(const std::vector<sfl_context *> &peers, const Overlap &o)
+{
     SFL_TRY(use_device(peers[0]));
     HIP_TRY(hipEventRecord(o.arrived, o.xstream));
     return SFL_OK;
@@ -453,13 +468,13 @@ int await_exchange(const std::vector<sfl_context *> &peers, const Overlap &o)
 // An exchange IN LINE with the compute stream's work.  With RCCL it still travels on the exchange
 // stream -- every operation of a communicator is issued to ONE stream, whatever the operator --
 // bracketed by the two events; in-process copies of a linked group go on the compute stream itself.
-int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows)
+int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows, int skip = 0)
 {
     if (rows <= 0 || ctx->nranks == 1) return SFL_OK;
-    if (!ctx->comm && !ctx->emulated) return exchange(peers, field, rows);
+    if (!ctx->comm && !ctx->emulated) return exchange(peers, field, rows, nullptr, skip);
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
-    SFL_TRY(start_exchange(peers, o, field, rows));
+    SFL_TRY(start_exchange(peers, o, field, rows, skip));
     return await_exchange(peers, o);
 }
 
@@ -487,17 +502,50 @@ int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &p
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
     bool pending = false;  // an exchange is in flight that the next launch's cut-adjacent rows need
+    bool behind_early = false;  // ... an early one, with a launch queued behind it: the next launch needs all of it
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
-        if (st0.kind == SFL_STEP_EXCHANGE) {  // (p exchanges are started by the launch before them)
+        if (st0.kind == SFL_STEP_EXCHANGE && st0.field == SFL_FIELD_PRESSURE && st0.g_begin > 0 && i + 1 < n &&
+            progs[0][i + 1].kind == SFL_STEP_SOR && progs[0][i + 1].nsweeps <= st0.g_begin) {
+            // EARLY exchange (slab_plan.cpp): the ghost rows are still valid as deep as the next launch needs for
+            // the OWNED rows.  Compute stream: that launch, owned rows only, whole -- no piece of it waits for the
+            // wire.  Exchange stream: the message (rows beyond that depth), then the same launch's passes on the
+            // ghost rows it feeds (output rows [g_begin, g0) and [g1, g_end)).  Both read p and write p_alt, on
+            // disjoint rows; the message lands in rows of p that the owned-row launch reads only into its
+            // throw-away rim.  The launch AFTER this one waits for `arrived`.
             if (pending) SFL_TRY(await_exchange(peers, o));
-            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows));
+            pending = behind_early = false;
+            SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, st0.rows, st0.g_begin, false));
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i + 1];
+                const int lo = c->rank > 0 ? c->g0 : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? c->g1 : st.g_end;
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));                                      // compute stream
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream));     // behind the message
+            }
+            SFL_TRY(mark_arrived(peers, o));
+            for (sfl_context *c : peers) {
+                std::swap(c->p, c->p_alt);
+                ++c->last_launches;
+            }
+            pending = behind_early = true;
+            ++i;  // the launch has been issued
+            continue;
+        }
+        if (st0.kind == SFL_STEP_EXCHANGE) {  // (classic p exchanges are started by the launch before them)
+            if (pending) SFL_TRY(await_exchange(peers, o));
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin));
             pending = true;
             continue;
         }
+        if (pending && behind_early) {  // the ghost rows relaxed behind an early exchange: needed whole, now
+            SFL_TRY(await_exchange(peers, o));
+            pending = behind_early = false;
+        }
         const bool sends_next = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE &&
-                                progs[0][i + 1].field == SFL_FIELD_PRESSURE;
+                                progs[0][i + 1].field == SFL_FIELD_PRESSURE && progs[0][i + 1].g_begin == 0;
         const int send_rows = sends_next ? progs[0][i + 1].rows : 0;
         const int ns = st0.nsweeps;
         if (pending) {
@@ -592,7 +640,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
     for (size_t i = 0; i < progs[0].size(); ++i) {
         const sfl_plan_step &st0 = progs[0][i];
         if (st0.kind == SFL_STEP_EXCHANGE) {
-            SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows));
+            SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
         } else {
             for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
         }

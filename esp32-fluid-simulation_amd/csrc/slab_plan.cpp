@@ -15,12 +15,13 @@ std::vector<int> sor_pass_plan(int iters, int fuse)
     return passes;
 }
 
-static sfl_plan_step exchange(int field, int rows)
+static sfl_plan_step exchange(int field, int rows, int skip = 0)
 {
     sfl_plan_step s{};
     s.kind = SFL_STEP_EXCHANGE;
     s.field = field;
     s.rows = rows;
+    s.g_begin = skip;
     return s;
 }
 
@@ -61,6 +62,50 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
     // exchange COUNT).  The first superstep needs no exchange: p is zero everywhere.
     const std::vector<int> passes = sor_pass_plan(iters, fuse);
     if (halo < fuse) halo = fuse;
+
+    if (multi && halo >= 2 * fuse) {
+        // EARLY exchanges (halo of at least two launches).  A launch needs `nsweeps` valid ghost rows to produce
+        // its own rows; everything deeper only feeds later launches.  So the halo for the next group of launches
+        // is sent ONE LAUNCH EARLY -- before the last launch e of the running group, while the ghost rows are
+        // still valid `n_e` deep: only the rows beyond that depth travel (skip = n_e, rows = halo - n_e), launch
+        // e produces the owned rows from what is already there, and the receiver repeats launch e's passes on
+        // the received rows (output rows own +- left, left <= halo - n_e).  The executor can therefore run the
+        // owned rows of launch e WHILE the message is in flight and relax the ghost rows behind it on the
+        // exchange stream: no launch is split, nothing on the compute stream waits for the wire except the
+        // launch after e.  Groups: the first may hold `halo` passes (p starts at zero: nothing to send), the
+        // following ones halo - n_e (what is left of the received rows after launch e's passes).
+        const size_t n = passes.size();
+        // extra[j] = ghost rows that must still be valid after launch j = passes of the launches up to and
+        // including the next exchange launch (whose owned rows are produced from what is there)
+        std::vector<int> xchg_before(n, 0), extra(n, 0);
+        int budget = halo;
+        for (size_t j = 0; j < n; ++j) {
+            if (passes[j] > budget) {  // launch j does not fit what is left: the exchange goes before launch j - 1
+                xchg_before[j - 1] = 1;
+                budget = halo - passes[j - 1];
+            }
+            budget -= passes[j];
+        }
+        for (size_t j = n; j-- > 0;) {
+            // rows needed after launch j: the following launches up to and including the next exchange launch
+            if (j + 1 < n) extra[j] = xchg_before[j + 1] ? passes[j + 1] : extra[j + 1] + passes[j + 1];
+        }
+        int deepest = 0;  // pass 1 of launch j relaxes its output rows +- (n_j - 1): rows of the right-hand side
+        for (size_t j = 0; j < n; ++j) deepest = extra[j] + passes[j] > deepest ? extra[j] + passes[j] : deepest;
+        if (deepest > 1) prog.push_back(exchange(SFL_FIELD_DIVERGENCE, deepest - 1));
+        for (size_t j = 0; j < n; ++j) {
+            if (xchg_before[j]) prog.push_back(exchange(SFL_FIELD_PRESSURE, halo - passes[j], passes[j]));
+            sfl_plan_step c{};
+            c.kind = SFL_STEP_SOR;
+            c.g_begin = g0 - extra[j] < 0 ? 0 : g0 - extra[j];
+            c.g_end = g1 + extra[j] > dim_y ? dim_y : g1 + extra[j];
+            c.nsweeps = passes[j];
+            c.first_colour = 0;
+            c.from_zero = j == 0;
+            prog.push_back(c);
+        }
+        return prog;
+    }
     std::vector<std::vector<int>> groups;
     for (int n : passes) {
         int sum = 0;

@@ -124,7 +124,11 @@ typedef struct sfl_plan_step {
     int32_t field;        /* EXCHANGE: SFL_FIELD_* whose halo rows are refreshed              */
     int32_t rows;         /* EXCHANGE: rows per side (sent from / received next to the owned
                              block); 0 on compute steps                                       */
-    int32_t g_begin;      /* compute: first output row (may extend into the ghost rows)       */
+    int32_t g_begin;      /* compute: first output row (may extend into the ghost rows).
+                             EXCHANGE: depth of the first row exchanged, counted from the cut
+                             (0 = the rows next to it): each rank sends its owned rows at depth
+                             [g_begin, g_begin + rows) and receives the neighbour's into the ghost
+                             rows at the same depth; the ghost rows nearer the cut are still valid */
     int32_t g_end;        /* compute: one past the last output row                            */
     int32_t nsweeps;      /* SOR: colour passes executed by this launch.  Pass j (1-based)
                              covers rows [g_begin-(nsweeps-j), g_end+(nsweeps-j)) clipped to
@@ -141,11 +145,17 @@ typedef struct sfl_plan_step {
 /* Program of one poisson_solve on slab `rank` of `nranks`: kernel = 1 (one colour pass per
  * launch, 1-row exchange before every pass but the first) or 2 (fused: `fuse` passes per
  * launch; launches are grouped into supersteps of at most `halo` passes in total, with ONE
- * exchange of that many rows of p before every superstep but the first -- ghost rows are
- * recomputed redundantly in between -- plus one exchange of the right-hand side up front).
- * halo is clamped to >= fuse; halo == fuse exchanges before every launch.  Writes at most `cap`
- * steps, returns the total in *n_steps.  Pure arithmetic, no GPU needed; the GPU executor
- * walks exactly this program.                                                                */
+ * exchange of p per superstep but the first -- ghost rows are recomputed redundantly in
+ * between -- plus one exchange of the right-hand side up front).
+ * halo is clamped to >= fuse; halo == fuse exchanges before every launch.
+ * halo >= 2 * fuse: EARLY exchanges.  The exchange of a superstep is issued one launch early,
+ * before the LAST launch of the previous superstep, while the ghost rows are still valid as deep
+ * as that launch needs for the owned rows (EXCHANGE.g_begin = its nsweeps, rows = halo - nsweeps);
+ * that launch's output extends `what the next superstep needs` into the ghost rows, i.e. its passes
+ * are repeated on the received rows.  An executor may run the owned rows of that launch while the
+ * message travels and the ghost rows behind it (sfl_api.cpp run_poisson_overlapped does).
+ * Writes at most `cap` steps, returns the total in *n_steps.  Pure arithmetic, no GPU needed;
+ * the GPU executor walks exactly this program.                                               */
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
                              int halo, sfl_plan_step *steps, int cap, int *n_steps);
 

@@ -66,23 +66,36 @@ def test_poisson_program_shape(sfl):
     for r in range(8):  # same skeleton on every rank, own rows as output
         assert [s.kind for s in progs[r]] == kinds
         assert all((s.g_begin, s.g_end) == sfl.slab_rows(8192, 8, r) for s in progs[r] if s.kind == S)
-    # supersteps: halo 32 at fuse 8 -> 5 groups of 4 launches, 4 exchanges of 32 rows, rhs 31 rows;
-    # inside a group the output range shrinks by 8 rows per launch down to the owned rows
+    # classic supersteps (halo < 2 * fuse): halo 12 at fuse 8 -> one launch per superstep, rhs 7 rows
+    prog = sfl.plan_poisson(8192, 8, 3, 80, 8, 2, 12)
+    assert [s.kind for s in prog] == [E, S] + [E, S] * 19 and all(s.g_begin == 0 for s in prog if s.kind == E)
+    # EARLY exchanges (halo >= 2 * fuse): halo 32 at fuse 8.  The first superstep holds 4 launches (32 passes);
+    # the exchange for the next one travels before its LAST launch, while the ghost rows are still valid 8 deep:
+    # rows at depth [8, 32) only, and that launch's output extends 24 rows into the ghost rows (its passes are
+    # repeated on what was received).  Afterwards 24 rows are left: supersteps of 3 launches.
     prog = sfl.plan_poisson(8192, 8, 3, 80, 8, 2, 32)
-    assert [s.kind for s in prog] == [E] + [S] * 4 + ([E] + [S] * 4) * 4
-    assert prog[0].field == sfl.capi.FIELD_DIVERGENCE and prog[0].rows == 31
-    assert all(s.rows == 32 for s in prog[1:] if s.kind == E)
+    assert [s.kind for s in prog] == [E] + [S] * 3 + ([E] + [S] * 3) * 5 + [E, S, S]
+    assert prog[0].field == sfl.capi.FIELD_DIVERGENCE and prog[0].rows == 31 and prog[0].g_begin == 0
+    assert all(s.rows == 24 and s.g_begin == 8 and s.field == sfl.capi.FIELD_PRESSURE for s in prog[1:] if s.kind == E)
     g0, g1 = sfl.slab_rows(8192, 8, 3)
-    assert [(s.g_begin, s.g_end) for s in prog[1:5]] == [(g0 - 24, g1 + 24), (g0 - 16, g1 + 16),
-                                                         (g0 - 8, g1 + 8), (g0, g1)]
+    assert [(s.g_begin, s.g_end) for s in prog[1:4]] == [(g0 - 24, g1 + 24), (g0 - 16, g1 + 16), (g0 - 8, g1 + 8)]
+    assert [(s.g_begin, s.g_end) for s in prog[5:8]] == [(g0 - 24, g1 + 24), (g0 - 16, g1 + 16), (g0 - 8, g1 + 8)]
+    assert (prog[-1].g_begin, prog[-1].g_end) == (g0, g1)
     assert [s.from_zero for s in prog if s.kind == S] == [1] + [0] * 19
+    # BASELINE config 4 as the library runs it (fuse 10, halo 64): 16 launches, the rhs + two early exchanges
+    prog = sfl.plan_poisson(8192, 8, 3, 80, 10, 2, 64)
+    assert [(s.rows, s.g_begin) for s in prog if s.kind == E] == [(59, 0), (54, 10), (54, 10)]
+    assert [s.kind for s in prog].index(E, 1) == 6 and sum(s.kind == S for s in prog) == 16
     # the domain's bottom / top slabs never reach outside the domain
     lo, hi = sfl.plan_poisson(8192, 8, 0, 80, 8, 2, 32), sfl.plan_poisson(8192, 8, 7, 80, 8, 2, 32)
     assert min(s.g_begin for s in lo if s.kind == S) == 0
     assert max(s.g_end for s in hi if s.kind == S) == 8192
     # a short last superstep exchanges only what it needs: 10 iters at fuse 8 = launches 8, 8, 4
-    prog = sfl.plan_poisson(400, 2, 0, 10, 8, 2, 16)
-    assert [(s.kind, s.rows or s.nsweeps) for s in prog] == [(E, 15), (S, 8), (S, 8), (E, 4), (S, 4)]
+    prog = sfl.plan_poisson(400, 2, 0, 10, 8, 2, 12)   # classic: launches 8 | 8 + 4
+    assert [(s.kind, s.rows or s.nsweeps) for s in prog] == [(E, 11), (S, 8), (E, 12), (S, 8), (S, 4)]
+    prog = sfl.plan_poisson(400, 2, 0, 10, 8, 2, 16)   # early: the 4-pass launch needs 4 ghost rows after launch 2
+    assert [(s.kind, s.rows or s.nsweeps, s.g_begin if s.kind == E else s.g_end - 200) for s in prog] == [
+        (E, 15, 0), (S, 8, 8), (E, 8, 8), (S, 8, 4), (S, 4, 0)]
     # baseline: zero fill, then exchange before every colour pass but the first
     prog = sfl.plan_poisson(100, 2, 1, 2, 8, 1)
     assert [s.kind for s in prog] == [Z, S, E, S, E, S, E, S]

@@ -1,0 +1,10 @@
+#!/bin/bash
+# r03: kernel timeline of one emulated rank's solve (rocprofv3 --kernel-trace only)
+set -u
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/r03_trace_${1:-x}
+rm -rf $O; mkdir -p $O
+shift
+rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python3 bench.py --steps 6 --warmup 3 --no-priming "$@" > $O/run.log 2>&1
+F=$(find $O -name "*kernel_trace.csv" | head -1)
+python3 tools/r03/timeline.py $F | tee $O/timeline.txt | head -60
