@@ -184,18 +184,30 @@ def host_cpu_model():
     return "unknown"
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the sources the fused SOR kernel is compiled from: counters measured on
+    another version of them are not this kernel's."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("sor_fused.hip", "sor_stream_core.h"):
+        with open(os.path.join(ROOT, PKG, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_record(grid, fuse, world):
-    """Counters of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json), or None when no entry matches this exact configuration."""
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
+    (entry, fresh) for the last entry that matches this exact configuration -- fresh = it was measured on the
+    kernel sources this run uses (kernel_source_sha16) -- or (None, False)."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
     except Exception:
-        return None
+        return None, False
     best = None
     for e in table:
         if e["grid"] == list(grid) and e["fuse"] == fuse and e["n_gpus"] == world:
             best = e    # later entries (later rounds) win
-    return best
+    return best, bool(best) and best.get("kernel_source_sha16") == kernel_source_hash()
 
 
 def parse_args(argv=None):
@@ -228,6 +240,8 @@ def parse_args(argv=None):
                          "the cuts are meaningless, so parity and the CPU baseline are skipped")
     ap.add_argument("--of", type=int, default=8, help="group size for --emulate-rank")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous plumbing only: the ranks touch no GPU (CPU test)")
     return ap.parse_args(argv)
@@ -237,35 +251,75 @@ def parse_args(argv=None):
 # parent: `python bench.py --gpus N` with N > 1 and no launcher around it
 # ---------------------------------------------------------------------------------------------
 def launch_ranks(args):
-    """Start one child per GPU and relay rank 0's JSON line.  This process never touches a GPU
-    (no HIP call, not even a device count): the children are fresh processes, nothing that has
-    initialised a GPU is ever replaced or forked."""
+    """Start one child per GPU, relay rank 0's JSON line, SUPERVISE them.  This process never touches a GPU
+    (no HIP call, not even a device count): the children are fresh processes, nothing that has initialised a GPU
+    is ever replaced or forked.  RCCL send / recv has no timeout: a rank that dies after the communicator is up
+    would leave its neighbours waiting for ever, so all children are polled; the first one that fails (or an
+    overall deadline, --launch-timeout seconds) takes the others down with it -- they are this process's own
+    children, addressed by PID -- and the launcher exits non-zero."""
+    import shutil
     import socket
+    import tempfile
+    import threading
     with socket.socket() as s:      # a free port for MASTER_PORT (RCCL's bootstrap picks its own)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     n = args.gpus
+    private = tempfile.mkdtemp(prefix="sfl_bench_")     # mode 0700: rendezvous file + parity arrays live here
     base = dict(os.environ)
     base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-                 "LOCAL_WORLD_SIZE": str(n), "SFL_RDZV_KEY": f"{os.getpid()}_{port}",
+                 "LOCAL_WORLD_SIZE": str(n), "SFL_RDZV_KEY": f"{os.getpid()}_{port}", "SFL_RDZV_DIR": private,
                  "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        # rank 0's stdout carries the JSON line; everybody else's goes to our stderr
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      stderr=sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait()
-        worst = rc if (rc != 0 and worst == 0) else worst
+    procs, lines = [], []
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            # rank 0's stdout carries the JSON line; everybody else's goes to our stderr
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=sys.stderr, text=True if r == 0 else None))
+        reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+        reader.start()
+        deadline = time.monotonic() + args.launch_timeout
+        worst, failed_at = 0, None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and failed_at is None:
+                worst, failed_at = bad[0], time.monotonic()
+                print(f"bench.py launcher: a rank exited with status {worst}; stopping the others", file=sys.stderr)
+            if all(c is not None for c in codes):
+                break
+            if failed_at is not None and time.monotonic() - failed_at > 2.0 or time.monotonic() > deadline:
+                if failed_at is None:
+                    worst = 124
+                    print(f"bench.py launcher: no result after {args.launch_timeout:.0f} s; stopping the ranks",
+                          file=sys.stderr)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                t_kill = time.monotonic() + 5.0
+                while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                    time.sleep(0.05)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                for p in procs:
+                    p.wait()
+                break
+            time.sleep(0.05)
+        reader.join(timeout=5.0)
+        for p in procs:
+            rc = p.returncode
+            worst = rc if (rc not in (0, None) and worst == 0) else worst
+    finally:
+        shutil.rmtree(private, ignore_errors=True)
     line = None
-    for l in (out0 or "").splitlines():
+    for l in lines:
+        l = l.rstrip("\n")
         if l.startswith("{"):
             line = l
-        else:
+        elif l:
             print(l, file=sys.stderr)
     if line:
         print(line, flush=True)
@@ -293,6 +347,10 @@ def run_rank(args):
 
     if args.dry_run:   # plumbing check without a GPU: broadcast, barrier, max, one JSON line
         token = rdzv.broadcast_bytes(os.urandom(16) if rank == 0 else None)
+        if os.environ.get("SFL_BENCH_TEST_FAIL_RANK") == str(rank):   # launcher test: a rank dies mid-run
+            os._exit(7)
+        if os.environ.get("SFL_BENCH_TEST_HANG"):                      # launcher test: ranks that never finish
+            time.sleep(3600)
         rdzv.barrier()
         top = rdzv.max([float(rank), 1.0])
         ranks = rdzv.all_gather({"rank": rank, "token": token.hex()})
@@ -446,31 +504,39 @@ def run_rank(args):
         else:
             # the ranks assemble the right-hand side in shared memory, rank 0 runs the reference on
             # the whole domain (the only way to get exact expectations), every rank checks its slab
-            shm = f"/dev/shm/sfl_bench_{os.environ.get('SFL_RDZV_KEY', str(os.getppid()))}"
-            if rank == 0:
-                d_all = np.lib.format.open_memmap(shm + "_d.npy", mode="w+", dtype=np.float32,
-                                                  shape=(dim_y, size))
-            rdzv.barrier()
-            if rank != 0:
-                d_all = np.load(shm + "_d.npy", mmap_mode="r+")
-            d_all[s.row_begin:s.row_end] = d_own
-            d_all.flush()
-            rdzv.barrier()
-            if rank == 0:
-                want_all, _ = cpu_reference_solve(np.ascontiguousarray(d_all), iters, min_seconds=0.0)
-                np.save(shm + "_p.npy", want_all)
-                del want_all
-            rdzv.barrier()
-            want = np.ascontiguousarray(np.load(shm + "_p.npy", mmap_mode="r")[s.row_begin:s.row_end])
-            bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
-            del d_all
-            bad = int(sum(rdzv.all_gather(bad)))
-            if rank == 0:
-                for suffix in ("_d.npy", "_p.npy"):
-                    try:
-                        os.unlink(shm + suffix)
-                    except OSError:
-                        pass
+            # (files of this run only: created exclusively -- never through a planted link -- under a name no other
+            # run uses, and always unlinked, also when a rank fails in between)
+            shm = f"/dev/shm/sfl_bench_{os.environ.get('SFL_RDZV_KEY', str(os.getppid()))}_{os.getuid()}"
+            d_all = None
+            try:
+                if rank == 0:
+                    for suffix in ("_d.npy", "_p.npy"):
+                        os.close(os.open(shm + suffix, os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW | os.O_WRONLY, 0o600))
+                    d_all = np.lib.format.open_memmap(shm + "_d.npy", mode="w+", dtype=np.float32,
+                                                      shape=(dim_y, size))
+                rdzv.barrier()
+                if rank != 0:
+                    d_all = np.load(shm + "_d.npy", mmap_mode="r+")
+                d_all[s.row_begin:s.row_end] = d_own
+                d_all.flush()
+                rdzv.barrier()
+                if rank == 0:
+                    want_all, _ = cpu_reference_solve(np.ascontiguousarray(d_all), iters, min_seconds=0.0)
+                    with open(shm + "_p.npy", "wb") as f:
+                        np.save(f, want_all)
+                    del want_all
+                rdzv.barrier()
+                want = np.ascontiguousarray(np.load(shm + "_p.npy", mmap_mode="r")[s.row_begin:s.row_end])
+                bad = int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+                bad = int(sum(rdzv.all_gather(bad)))
+            finally:
+                del d_all
+                if rank == 0:
+                    for suffix in ("_d.npy", "_p.npy"):
+                        try:
+                            os.unlink(shm + suffix)
+                        except OSError:
+                            pass
         parity = {"config": f"poisson_solve {size}x{dim_y} fp32, {iters} iters, omega 1.96, dx 1, the timed "
                             f"solve's own output vs the reference CPU loop on the same rhs (poisson.cpp:114-125)",
                   "bit_exact": bad == 0, "cells": cells, "mismatching_cells": bad,
@@ -501,7 +567,8 @@ def run_rank(args):
         bytes_per_launch = SOR_BYTES_PER_CELL_ITER * (cells / world) * iters / launches
         algorithmic_gbs = bytes_per_launch / avg_launch_s / 1e9
         name, cus, mem = sfl.device_info(local_rank)
-        pmc = pmc_record((size, dim_y), info["fuse"], world)
+        pmc_any, pmc_fresh = pmc_record((size, dim_y), info["fuse"], world)
+        pmc = pmc_any if pmc_fresh else None    # counters of another kernel version are not quoted
         # The contract names HBM or MFMA as the bound; for this stencil it is HBM (DESIGN.md 4.1 has the
         # finer picture: a launch lasts as long as one wave's chain of iterations, ~0.87 of the access
         # pattern's memory floor).  `achieved` = HBM bytes the launch really moves / its duration, the
@@ -526,7 +593,13 @@ def run_rank(args):
                                     "compulsory 12 B per cell per launch (no PMC pass committed for this "
                                     "configuration) / launch duration by HIP events"),
             "traffic": traffic,
-            "traffic_source": pmc["source"] if pmc else None,
+            "traffic_source": pmc["source"] if pmc else ("stale: " + pmc_any["source"] + " was measured on other kernel "
+                                                         "sources; compulsory bytes used" if pmc_any else None),
+            "kernel_source_sha16": kernel_source_hash(),
+            # the same bytes over the committed profile's OWN steady-state launch time (rocprofv3 kernel trace)
+            "frac_from_profile": (traffic / (pmc["avg_launch_us_rocprof"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            if pmc and pmc.get("avg_launch_us_rocprof") else None,
+            "avg_launch_us_profile": pmc.get("avg_launch_us_rocprof") if pmc else None,
             "compulsory_bytes_per_launch": compulsory,
             "kernel": "sor_fused_kernel" if info["fuse"] > 1 else "sor_half_sweep_kernel",
             "avg_launch_us": avg_launch_s * 1e6,
@@ -544,9 +617,10 @@ def run_rank(args):
                                         "FMA: the reference rounds every product and sum)",
                      "issued_over_useful": (pmc["valu_wave_insts_per_launch"] / useful_insts)
                      if pmc and pmc.get("valu_wave_insts_per_launch") else None,
-                     "note": "the shader clock under this kernel is ~1.2 GHz (power), measured with clock64() "
-                             "inside the kernel (profiles/r02_rhs_read_ahead.txt): at that clock the SIMDs issue "
-                             "throughout; the peak above is the nominal 2.4 GHz"},
+                     "note": "the package runs at its 1400 W power cap under this kernel and clocks 1.6-2.1 GHz depending "
+                             "on the box (s_memtime against s_memrealtime in every wave, rocm-smi: "
+                             "profiles/r03_clock_probe_ns16_8192.txt, r03_clock_smi_during_kernel.txt); the peak above "
+                             "is the nominal 2.4 GHz"},
         }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",

@@ -92,6 +92,7 @@ SIGNATURES = {
     "sfl_slab_of": (_i, [_ctx, _pi, _pi, _pi, _pi]),
     "sfl_comm_unique_id": (_i, [C.c_void_p, _sz]),
     "sfl_comm_attach": (_i, [_ctx, C.c_void_p, _sz]),
+    "sfl_comm_check_options": (_i, [_ctx]),
     "sfl_comm_loopback": (_i, [_ctx, _i]),
     "sfl_comm_emulate": (_i, [_ctx]),
     "sfl_group_link": (_i, [C.POINTER(_ctx), _i]),

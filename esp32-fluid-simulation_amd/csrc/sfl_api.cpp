@@ -375,17 +375,21 @@ int effective_halo(const sfl_context *c, int fuse)
 // ---- poisson_solve executor --------------------------------------------------------------
 // One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
 // all pieces read c->p and write c->p_alt; the caller swaps once per step).
+// `in` / `out` = the step's input and output arrays (null: c->p / c->p_alt); `on` = stream (null: the compute stream)
 int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
-                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr)
+                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const float *in = nullptr,
+                    float *out = nullptr)
 {
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
+    if (!in) in = c->p;
+    if (!out) out = c->p_alt;
     SFL_TRY(use_device(c));
     // Slabs that outgrow the Infinity Cache (256 MB; p + d of 48 M cells = 384 MB) reverse the stream direction of
     // every tile from one launch to the next: a launch then begins on the rows its predecessor read and wrote
     // last, the only ones still cached (8192^2: -3 % per launch; no gain or a small loss on slabs that fit:
     // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
     const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
-    HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, c->p_alt, st.from_zero ? nullptr : c->p, c->div, c->geom,
+    HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, out, st.from_zero ? nullptr : in, c->div, c->geom,
                                   sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
                                   prm, c->opt_sor_rows, sweep));
     return SFL_OK;
@@ -496,11 +500,31 @@ int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, i
 // of the step's output and writes ghost rows nobody else touches meanwhile, so the pieces are
 // independent and the result is the bits of the plain order.  With SFL_OPT_SOR_OVERLAP = 0, and for
 // the baseline kernel, every step is issued whole on the compute stream.
+int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                                 const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm,
+                                 const Overlap &o);
+
 int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &peers,
                            const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm)
 {
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
+    const int rc = run_poisson_overlapped_steps(ctx, peers, progs, prm, o);
+    if (rc != SFL_OK) {
+        // a launch or an RCCL call failed half way: nothing of this solve may still be in flight on the exchange
+        // stream when the caller looks at (or destroys) the context; the error message of the failure is kept
+        const std::string why = g_error;
+        (void)hipStreamSynchronize(o.xstream);
+        (void)hipStreamSynchronize(o.compute);
+        g_error = why;
+    }
+    return rc;
+}
+
+int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                                 const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm,
+                                 const Overlap &o)
+{
     bool pending = false;  // an exchange is in flight that the next launch's cut-adjacent rows need
     bool behind_early = false;  // ... an early one, with a launch queued behind it: the next launch needs all of it
     const size_t n = progs[0].size();
@@ -583,7 +607,7 @@ int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &p
                 const int lo = c->rank > 0 ? std::min(c->g0 + send_rows, st.g_end) : st.g_begin;
                 const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - send_rows, lo) : st.g_end;
                 SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end));  // both bands, one launch
-                std::swap(c->p, c->p_alt);  // the exchange sends from / receives into the step's output
+                std::swap(c->p, c->p_alt);  // ONE swap per step: the exchange sends from / receives into its output
             }
             SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, send_rows));
             pending = true;
@@ -592,9 +616,8 @@ int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &p
                 const sfl_plan_step &st = progs[k][i];
                 const int lo = c->rank > 0 ? std::min(c->g0 + send_rows, st.g_end) : st.g_begin;
                 const int hi = c->rank < c->nranks - 1 ? std::max(c->g1 - send_rows, lo) : st.g_end;
-                std::swap(c->p, c->p_alt);  // back: the remaining rows read the step's input
-                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));
-                std::swap(c->p, c->p_alt);
+                // the remaining rows: from the step's input (now p_alt) into its output (now p)
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi, 0, 0, nullptr, c->p_alt, c->p));
                 ++c->last_launches;
             }
             ++i;  // the exchange step has been issued
@@ -884,6 +907,7 @@ int sfl_destroy(sfl_context *c)
         for (sfl_context *m : g->members) m->group.reset();
     }
     c->keepalive.reset();
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);  // nothing of the communicator may still be queued
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
                     (void *)c->sor_block, (void *)c->halo_flag,
@@ -1012,6 +1036,59 @@ int sfl_comm_unique_id(void *id_out, size_t id_bytes)
     return SFL_OK;
 }
 
+// Everything that must be identical on all ranks of a communicator for their programs to match: the domain,
+// the group size and every option a plan or an exchange depends on.
+constexpr int kOptionBlockInts = 16;
+static void option_block(const sfl_context *c, int *b)
+{
+    const int v[kOptionBlockInts] = {SFL_ABI_VERSION, c->dim_x, c->gdim_y, c->nranks, c->opt_sor_kernel, c->opt_sor_fuse,
+                                     c->opt_sor_halo, c->opt_sor_overlap, c->opt_advect_halo, c->opt_fuse_projection,
+                                     c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, 0, 0, 0};
+    memcpy(b, v, sizeof v);
+}
+
+int sfl_comm_check_options(sfl_context *c)
+{
+    if (!c) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (!c->comm) return fail(SFL_ERR_STATE, "no communicator attached");
+    SFL_TRY(use_device(c));
+    Overlap o;
+    SFL_TRY(overlap_of(c, &o));
+    int mine[kOptionBlockInts];
+    option_block(c, mine);
+    int *dev = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(int) * kOptionBlockInts * (size_t)(c->nranks + 1)));
+    std::vector<int> all((size_t)kOptionBlockInts * c->nranks);
+    int rc = SFL_OK;
+    do {  // (single exit: the scratch buffer is freed on every path)
+        if (hipMemcpy(dev, mine, sizeof mine, hipMemcpyHostToDevice) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = fail(SFL_ERR_HIP, "option block upload failed");
+            break;
+        }
+        const ncclResult_t r = ncclAllGather(dev, dev + kOptionBlockInts, kOptionBlockInts, ncclInt32, c->comm, o.xstream);
+        if (r != ncclSuccess) {
+            rc = fail(SFL_ERR_RCCL, "ncclAllGather of the option block failed: %s", ncclGetErrorString(r));
+            break;
+        }
+        if (hipStreamSynchronize(o.xstream) != hipSuccess ||
+            hipMemcpy(all.data(), dev + kOptionBlockInts, all.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(SFL_ERR_HIP, "option block download failed");
+            break;
+        }
+        for (int r2 = 0; r2 < c->nranks && rc == SFL_OK; ++r2)
+            for (int k = 0; k < kOptionBlockInts; ++k)
+                if (all[(size_t)r2 * kOptionBlockInts + k] != mine[k]) {
+                    rc = fail(SFL_ERR_STATE, "rank %d and rank %d disagree on option-block word %d (%d vs %d): every rank "
+                              "of a communicator must be created for the same domain and carry the same options",
+                              c->rank, r2, k, mine[k], all[(size_t)r2 * kOptionBlockInts + k]);
+                    break;
+                }
+    } while (false);
+    (void)hipFree(dev);
+    return rc;
+}
+
 int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
 {
     if (!c || !id || id_bytes < sizeof(ncclUniqueId)) return fail(SFL_ERR_INVALID, "bad arguments");
@@ -1020,7 +1097,9 @@ int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     NCCL_TRY(ncclCommInitRank(&c->comm, c->nranks, uid, c->rank));
-    return SFL_OK;
+    // the ranks are separate processes: a rank created for another domain or with other options would run a
+    // different program (mismatched sends / receives: a hang or silently wrong halos) -- refuse it here
+    return sfl_comm_check_options(c);
 }
 
 int sfl_comm_emulate(sfl_context *c)
@@ -1041,10 +1120,16 @@ int sfl_comm_loopback(sfl_context *c, int rows)
     SFL_TRY(use_device(c));
     const size_t bytes = (size_t)rows * c->dim_x * 4;
     const size_t off = c->owned_offset_cells();
+    Overlap o;  // like every operation of the communicator: on the exchange stream, between the two events
+    SFL_TRY(overlap_of(c, &o));
+    HIP_TRY(hipEventRecord(o.ready, o.compute));
+    HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
     NCCL_TRY(ncclGroupStart());
-    NCCL_TRY(ncclSend(c->div + off, bytes, ncclChar, c->rank, c->comm, c->stream));
-    NCCL_TRY(ncclRecv(c->p + off, bytes, ncclChar, c->rank, c->comm, c->stream));
+    NCCL_TRY(ncclSend(c->div + off, bytes, ncclChar, c->rank, c->comm, o.xstream));
+    NCCL_TRY(ncclRecv(c->p + off, bytes, ncclChar, c->rank, c->comm, o.xstream));
     NCCL_TRY(ncclGroupEnd());
+    HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+    HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
     return SFL_OK;
 }
 
@@ -1676,8 +1761,6 @@ int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, flo
     if (k) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_KERNEL, atoi(k)));
     const char *f = getenv("SFL_SOR_FUSE");
     if (f) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_FUSE, atoi(f)));
-    const char *l = getenv("SFL_SOR_LANE_CELLS");
-    if (l) SFL_TRY(sfl_set_option(t.c, SFL_OPT_SOR_LANE_CELLS, atoi(l)));
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_DIVERGENCE, div, (size_t)dim_x * dim_y * 4));
     SFL_TRY(sfl_poisson_solve(t.c, dx, iters, omega));
     return t.done(sfl_download(t.c, SFL_FIELD_PRESSURE, p, (size_t)dim_x * dim_y * 4));

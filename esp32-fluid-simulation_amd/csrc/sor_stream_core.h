@@ -9,15 +9,14 @@
 // poisson.cpp:14-112 on one tile, in ONE sweep over the tile's rows, reading p and d once
 // and writing p once.  Bit-identical to running the passes one after the other.
 //
-// Tile = 64 lanes x (2 or 4) columns x a run of rows streamed bottom-up.  A lane's value type
-// V holds its cells of ONE colour in a row: with 2 cells per lane V = float (cell `a` at an even
-// column x_a, cell `b` at x_a + 1); with 4 cells per lane V = two packed floats, a = {x_a,
-// x_a + 2}, b = {x_a + 1, x_a + 3}, and every relaxation is carried out with packed fp32
-// instructions (plain fp32 VALU ops issue at 4 cycles per wave on gfx950, packed ones process
-// two floats per lane in the same 4 cycles).  from_lower_lane / from_upper_lane shift a
-// colour vector by one position of that colour towards higher / lower columns.  Colours: a cell is "E" when (column + row) is even
-// (updated by the first pass of an iteration, poisson.cpp:22) and "O" otherwise.  In a row of
-// even parity the E cell of a lane is `a`, in an odd row it is `b`.
+// Tile = 64 lanes x 2 columns (128 columns) x a run of rows streamed bottom-up (or top-down: FLIP).  A lane's
+// value type V holds its cell of ONE colour in a row: V = float, cell `a` at the even column x_a, cell `b` at
+// x_a + 1.  (Rounds 1 and 2 also carried 4-cells-per-lane flavours on packed and on scalar fp32; a plain fp32
+// instruction of a wave64 occupies the SIMD for 2 cycles, a packed one for 4, and neither flavour was ever
+// faster: DESIGN.md 4.1.)  from_lower_lane / from_upper_lane shift a colour vector by one position of that
+// colour towards higher / lower columns.  Colours: a cell is "E" when (column + row) is even (updated by the
+// first pass of an iteration, poisson.cpp:22) and "O" otherwise.  In a row of even parity the E cell of a
+// lane is `a`, in an odd row it is `b`.
 //
 // Dependencies (5-point stencil, neighbours always have the other colour):
 //   E_m[r] = relax(E_{m-1}[r]; W/E from O_{m-1}[r]; S = O_{m-1}[r-1]; N = O_{m-1}[r+1]; d_E[r])

@@ -43,8 +43,13 @@ def _recv(sock: socket.socket):
 
 
 def rendezvous_file(key: str | None = None) -> str:
+    """bench.py's launcher hands its ranks a private directory (SFL_RDZV_DIR, mode 0700, removed when it exits);
+    under other launchers the file lives in the temp directory under a per-user name and is created exclusively."""
     key = key or os.environ.get("SFL_RDZV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
-    return os.path.join(tempfile.gettempdir(), f"sfl_rdzv_{key}")
+    private = os.environ.get("SFL_RDZV_DIR")
+    if private and os.path.isdir(private):
+        return os.path.join(private, f"sfl_rdzv_{key}")
+    return os.path.join(tempfile.gettempdir(), f"sfl_rdzv_{os.getuid()}_{key}")
 
 
 class Rendezvous:
@@ -65,8 +70,10 @@ class Rendezvous:
             srv.bind(("127.0.0.1", 0))
             srv.listen(world)
             nonce = base64.b16encode(os.urandom(8)).decode()
-            tmp = f"{self._path}.{os.getpid()}"
-            with open(tmp, "w") as f:
+            tmp = f"{self._path}.{os.getpid()}.{nonce}"
+            # O_EXCL | O_NOFOLLOW: never written through a link somebody else planted under a guessable name
+            fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW | os.O_WRONLY, 0o600)
+            with os.fdopen(fd, "w") as f:
                 json.dump({"port": srv.getsockname()[1], "nonce": nonce, "world": world}, f)
             os.replace(tmp, self._path)     # atomic: readers see the old file or the new one
             by_rank: dict[int, socket.socket] = {}

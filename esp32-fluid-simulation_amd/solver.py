@@ -116,6 +116,10 @@ class Solver:
     def comm_attach(self, unique_id: bytes):
         capi.check(self._lib.sfl_comm_attach(self._h, unique_id, len(unique_id)))
 
+    def comm_check_options(self):
+        """Collective: every rank of the communicator must carry the same domain and options (sfl_comm_check_options)."""
+        capi.check(self._lib.sfl_comm_check_options(self._h))
+
     def comm_loopback(self, rows: int):
         capi.check(self._lib.sfl_comm_loopback(self._h, rows))
 

@@ -223,6 +223,11 @@ SFL_API int sfl_slab_of(sfl_context *ctx, int *row_begin, int *row_end, int *ran
  *     torch.distributed broadcast), every rank attaches.  id_bytes = 128.                  */
 SFL_API int sfl_comm_unique_id(void *id_out, size_t id_bytes);
 SFL_API int sfl_comm_attach(sfl_context *ctx, const void *id, size_t id_bytes);
+/* Collective over the attached communicator (called by sfl_comm_attach itself; call it again after changing
+ * options): all-gathers domain, group size and every option the solve's program depends on, and fails with
+ * SFL_ERR_STATE on the ranks that differ from any other -- mismatched programs would otherwise hang in a
+ * send / receive or exchange the wrong rows.  Synchronises the context's streams.                       */
+SFL_API int sfl_comm_check_options(sfl_context *ctx);
 /* RCCL bring-up check for boxes with a single GPU (a communicator cannot hold two ranks of one
  * device): inside one ncclGroup, send the first `rows` owned rows of the divergence field to
  * this rank itself and receive them into the first `rows` owned rows of the pressure field --

@@ -89,3 +89,27 @@ def test_bench_parent_reports_a_failing_rank():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr
+
+
+def test_self_launcher_stops_the_other_ranks_when_one_dies():
+    """RCCL send / recv has no timeout: the launcher supervises its children, and a rank that dies takes the others
+    (here: waiting in a barrier for ever) down with it -- non-zero exit within seconds, no JSON line."""
+    import time
+    env = dict(os.environ, SFL_BENCH_TEST_FAIL_RANK="1")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    # (the survivors may notice the dead socket and fail on their own before the launcher stops them: either way
+    # the launcher reports a failure, promptly)
+    assert r.returncode != 0, (r.returncode, r.stderr[-2000:])
+    assert time.monotonic() - t0 < 60
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "bench.py launcher: a rank exited with status" in r.stderr
+
+
+def test_self_launcher_deadline():
+    """--launch-timeout: ranks that never finish are stopped and the launcher reports 124."""
+    env = dict(os.environ, SFL_BENCH_TEST_FAIL_RANK="none", SFL_BENCH_TEST_HANG="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "3"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])

@@ -203,6 +203,10 @@ def test_rccl_single_rank_communicator(sfl, oracle):
         got = s.download(sfl.capi.FIELD_PRESSURE)
         assert_bit_equal(got[:17], d[:17], "loopback rows")
         assert not got[17:].any()
+        # the option block travels through a real ncclAllGather (attach did it once already): still in agreement
+        s.set_option(sfl.capi.OPT_SOR_FUSE, 6)
+        s.comm_check_options()
+        assert s.get_option(sfl.capi.OPT_TRANSPORT) == 1
 
 
 def bench_rhs(sfl, size, dim_y=None):
@@ -481,10 +485,10 @@ def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks)
 
 
 def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
-    """The program bench.py runs at --gpus 8 (8192^2 in eight 1024-row slabs, every option on auto:
-    fuse 10, halo 64, two supersteps at 40 iterations so that p is exchanged as well as the rhs),
-    executed by eight virtual ranks on one GPU, against the oracle."""
-    dim, iters, nranks = 8192, 40, 8
+    """BASELINE config 4 exactly as bench.py runs it at --gpus 8 (8192^2 in eight 1024-row slabs, 80 iterations,
+    every option on auto: fuse 10, halo 64 -> 16 launches, the rhs exchange and two early p exchanges with their
+    ghost-row launches on the exchange stream), executed by eight virtual ranks on one GPU, against the oracle."""
+    dim, iters, nranks = 8192, 80, 8
     rng = np.random.default_rng(88)
     d = (rng.standard_normal((dim, dim)) * 0.1).astype(np.float32)
     want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
@@ -501,7 +505,7 @@ def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
         for s in slabs:
             s.close()
     assert_bit_equal(got, want, "8192^2 in 8 slabs, auto settings")
-    assert info["fuse"] == 10 and info["launches"] == 8 and info["exchanges"] == 2 == plan_exchanges(sfl, dim, nranks, iters, 10)
+    assert info["fuse"] == 10 and info["launches"] == 16 and info["exchanges"] == 3 == plan_exchanges(sfl, dim, nranks, iters, 10)
 
 
 @pytest.mark.parametrize("dim_y,fuse", [(1600, 10), (3200, 16)])

@@ -20,15 +20,21 @@ def _devices():
     return importlib.import_module("esp32-fluid-simulation_amd").device_count()
 
 
-@pytest.mark.parametrize("nranks,size,iters,halo", [(2, 2048, 40, 0), (2, 1024, 24, 16), (4, 2048, 40, 0), (8, 4096, 30, 0)])
-def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo):
+# (8, 8192, 80) is BASELINE config 4, (2 / 4, 8192, 80) its other scaling points, (8, 16384, 200) config 5 -- exactly as
+# bench.py runs them; the smaller grids exercise classic (halo < 2 x fuse) and early exchanges, with and without overlap
+@pytest.mark.parametrize("nranks,size,iters,halo,overlap", [
+    (2, 2048, 40, 0, 1), (2, 1024, 24, 16, 1), (2, 1024, 24, 12, 0), (4, 2048, 40, 0, 1), (8, 4096, 30, 0, 1),
+    (2, 8192, 80, 0, 1), (4, 8192, 80, 0, 1), (8, 8192, 80, 0, 1), (8, 8192, 80, 0, 0), (8, 16384, 200, 0, 1)])
+def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, overlap):
     if _devices() < nranks:
         pytest.skip(f"needs {nranks} GPUs, {_devices()} visible")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--size", str(size),
-           "--iters", str(iters), "--steps", "2", "--warmup", "1", "--sim-steps", "1"]
+           "--iters", str(iters), "--steps", "2", "--warmup", "1", "--sim-steps", "1", "--no-priming"]
     if halo:
         cmd += ["--sor-halo", str(halo)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+    if not overlap:
+        cmd += ["--no-overlap"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode == 0, r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
