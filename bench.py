@@ -375,7 +375,6 @@ def run_rank(args):
         s = sfl.Solver(size, dim_y, device=local_rank, rank=args.emulate_rank, nranks=args.of)
         s.comm_emulate()
         args.no_cpu_baseline = True
-        args.sim_steps = 0
     else:
         s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
     if args.no_overlap:
@@ -473,8 +472,8 @@ def run_rank(args):
             except sfl.SflError as e:
                 failed.append(str(e))
 
-        if world > 1:   # generous advection halo: the projected velocity is not bounded by vamp
-            s.set_option(capi.OPT_ADVECT_HALO, 32)
+        # (slabs run on the automatic advection halo, the default: exact for the velocity advection, guessed and
+        # checked after the step for the dye -- no host round trip inside a step, never an SFL_ERR_HALO)
         dtf = np.float32(1 / 30.0)
         # the downloads above left the GPU idle: bring it back to its sustained clocks with untimed steps
         for _ in range(1 if args.no_priming else 12):
@@ -553,6 +552,7 @@ def run_rank(args):
             "cell_iters_per_sec_of_this_rank": cells * iters * args.steps / elapsed,
             "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
+            "sim_step_us": (1e6 / sim_sps) if sim_sps else None, **({"sim_steps_note": sim_note} if sim_note else {}),
             "note": "one rank's program alone on one GPU, halo messages as self-copies of the same size on the "
                     "exchange stream (sfl_comm_emulate); values next to the cuts are meaningless",
             "device": name}), flush=True)

@@ -131,8 +131,19 @@ struct sfl_context {
     // ghost rows (allocated on first need; sized for the 12-byte dye element)
     int *d_reach = nullptr;
     void *gather_buf = nullptr;
+    // ... without a host round trip inside sfl_step (slab_step_auto): the dye advection runs on a GUESSED halo,
+    // the true reach of its back-traces and an "a back-trace left the halo" flag are reduced on the device,
+    // land in pinned host memory behind ev_report, and are examined when the NEXT call touches the context
+    int *d_report = nullptr;       // device {reach below, reach above, flag, 0}
+    int *h_report = nullptr;       // pinned host copy
+    hipEvent_t ev_report = nullptr;
+    bool color_unsettled = false;  // a dye advection on a guessed halo has not been checked yet
+    float unsettled_dt = 0.0f;
+    int known_reach = -1;          // reach of the back-traces of the CURRENT velocity at known_dt (-1: unknown)
+    uint64_t known_epoch = 0, vel_epoch = 1;   // vel_epoch counts the writes to the velocity field
+    float known_dt = 0.0f;
 
-    int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 4, opt_sor_rows = 0,
+    int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
         opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1;
 
@@ -923,6 +934,9 @@ int sfl_destroy(sfl_context *c)
         (void)hipStreamSynchronize(c->xstream);
         (void)hipStreamDestroy(c->xstream);
     }
+    if (c->d_report) (void)hipFree(c->d_report);
+    if (c->h_report) (void)hipHostFree(c->h_report);
+    if (c->ev_report) (void)hipEventDestroy(c->ev_report);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_arrived) (void)hipEventDestroy(c->ev_arrived);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1172,20 +1186,25 @@ int sfl_group_link(sfl_context **ctxs, int n)
     return SFL_OK;
 }
 
+static int settle_color(sfl_context *ctx);
+
 int sfl_upload(sfl_context *c, int field, const void *host, size_t bytes)
 {
     if (!c || !host) return fail(SFL_ERR_INVALID, "NULL argument");
+    SFL_TRY(settle_color(c));
     const size_t eb = field_elem_bytes(field);
     if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
     const size_t want = (size_t)(c->g1 - c->g0) * c->dim_x * eb;
     if (bytes != want) return fail(SFL_ERR_INVALID, "field %d: got %zu bytes, slab holds %zu", field, bytes, want);
     SFL_TRY(ensure_field(c, field));
+    if (field == SFL_FIELD_VELOCITY) ++c->vel_epoch;
     return upload_raw(c, field_ptr(c, field), host, eb);
 }
 
 int sfl_download(sfl_context *c, int field, void *host, size_t bytes)
 {
     if (!c || !host) return fail(SFL_ERR_INVALID, "NULL argument");
+    SFL_TRY(settle_color(c));
     const size_t eb = field_elem_bytes(field);
     if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
     const size_t want = (size_t)(c->g1 - c->g0) * c->dim_x * eb;
@@ -1197,6 +1216,7 @@ int sfl_download(sfl_context *c, int field, void *host, size_t bytes)
 int sfl_field_device_ptr(sfl_context *c, int field, void **dev_ptr)
 {
     if (!c || !dev_ptr) return fail(SFL_ERR_INVALID, "NULL argument");
+    SFL_TRY(settle_color(c));
     const size_t eb = field_elem_bytes(field);
     if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
     SFL_TRY(ensure_field(c, field));
@@ -1219,7 +1239,16 @@ struct AdvectPlan {
     int halo = 0;         // rows to exchange per side (fixed or measured)
     bool gather = false;  // sample a gathered copy of the whole field instead
     bool flag = true;     // fixed halo: let the kernel report a back-trace that leaves it
+    bool report = false;  // ... into the context's reach report (a guessed halo, checked by settle_color)
+                          // instead of the error flag sfl_synchronize turns into SFL_ERR_HALO
 };
+
+int *advect_flag(sfl_context *c, const AdvectPlan &plan)
+{
+    if (c->nranks == 1 || plan.gather) return nullptr;
+    if (plan.report) return c->d_report + 2;
+    return plan.flag ? c->halo_flag : nullptr;
+}
 
 int measure_reach(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int *reach_out)
 {
@@ -1316,9 +1345,15 @@ int gather_field(sfl_context *ctx, const std::vector<sfl_context *> &peers, int 
 }
 
 // ---- operators ---------------------------------------------------------------------------
+static int settle_color(sfl_context *ctx);
+
+static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
+                                   const AdvectPlan &plan);
+
 int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1326,6 +1361,16 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
     }
     AdvectPlan plan;
     SFL_TRY(plan_advect(ctx, peers, dt, &plan));
+    return advect_velocity_planned(ctx, peers, dt, no_slip, plan);
+}
+
+static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
+                                   const AdvectPlan &plan)
+{
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    }
     if (plan.gather)
         SFL_TRY(gather_field(ctx, peers, SFL_FIELD_VELOCITY));
     else
@@ -1340,16 +1385,20 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
         else
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
                                              clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
-                                             no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr,
-                                             nullptr, c->opt_advect_kernel));
+                                             no_slip != 0, advect_flag(c, plan), nullptr, c->opt_advect_kernel));
         std::swap(c->vel, c->vel_tmp);  // ino:255
+        ++c->vel_epoch;
     }
     return SFL_OK;
 }
 
+static int advect_color_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
+                                const AdvectPlan &plan);
+
 int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1358,6 +1407,17 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
     }
     AdvectPlan plan;
     SFL_TRY(plan_advect(ctx, peers, dt, &plan));
+    return advect_color_planned(ctx, peers, dt, no_slip, plan);
+}
+
+static int advect_color_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
+                                const AdvectPlan &plan)
+{
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+        SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    }
     if (plan.gather)
         SFL_TRY(gather_field(ctx, peers, SFL_FIELD_COLOR));
     else
@@ -1372,8 +1432,7 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
         else
             HIP_TRY(sfl::launch_advect_vec3uq32(c->stream, c->col_tmp, c->col, c->vel, c->geom, c->g0, c->g1,
                                                 clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
-                                                no_slip != 0, c->nranks > 1 && plan.flag ? c->halo_flag : nullptr,
-                                                nullptr, c->opt_advect_kernel));
+                                                no_slip != 0, advect_flag(c, plan), nullptr, c->opt_advect_kernel));
         std::swap(c->col, c->col_tmp);  // ino:286
     }
     return SFL_OK;
@@ -1382,6 +1441,7 @@ int sfl_advect_color(sfl_context *ctx, float dt, int no_slip)
 int sfl_calculate_divergence(sfl_context *ctx, float dx)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1400,12 +1460,14 @@ int sfl_calculate_divergence(sfl_context *ctx, float dx)
 int sfl_poisson_solve(sfl_context *ctx, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     return run_poisson(ctx, dx, iters, omega);
 }
 
 int sfl_subtract_gradient(sfl_context *ctx, float dx)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1417,6 +1479,7 @@ int sfl_subtract_gradient(sfl_context *ctx, float dx)
         SFL_TRY(use_device(c));
         HIP_TRY(sfl::launch_subtract_gradient(c->stream, c->vel, c->p, c->geom, c->g0, c->g1,
                                               two_dx_inv, c->opt_advect_kernel));
+        ++c->vel_epoch;
     }
     return SFL_OK;
 }
@@ -1493,15 +1556,17 @@ static int apply_queued_forces(sfl_context *c)
 {
     int n = 0;
     SFL_TRY(stage_queued_forces(c, &n));
-    if (n > 0)
+    if (n > 0) {
         HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
                                          c->d_force_vel, n));
+        ++c->vel_epoch;
+    }
     return SFL_OK;
 }
 
 
 // ino:276 + ino:281-287 in one pass: project each cell's own velocity, advect the dye with it.
-static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
+static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int halo, bool report)
 {
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
@@ -1511,16 +1576,17 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx)
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
     SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, ctx->opt_advect_halo));
+    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, halo));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
-        const int h = c->nranks > 1 ? c->opt_advect_halo : 0;
+        const int h = c->nranks > 1 ? halo : 0;
         HIP_TRY(sfl::launch_project_advect_vec3uq32(
             c->stream, c->col_tmp, c->col, c->vel, c->p, c->geom, c->g0, c->g1, clip_lo(c, c->g0 - h),
-            clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? c->halo_flag : nullptr, two_dx_inv,
-            c->opt_advect_kernel));
+            clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? (report ? c->d_report + 2 : c->halo_flag) : nullptr,
+            two_dx_inv, c->opt_advect_kernel));
         std::swap(c->col, c->col_tmp);  // ino:286
+        ++c->vel_epoch;                 // the projection rewrote the velocity
     }
     return SFL_OK;
 }
@@ -1582,10 +1648,147 @@ static int small_grid_step(sfl_context *c, float dt, float dx, int iters, float 
     return SFL_OK;
 }
 
+// ---- automatic advection halo without a host round trip inside the step ------------------------------------
+// The reach of the back-traces depends on the velocity, known only on the device.  Two facts make a step without
+// a mid-step read-back possible:
+//   * the velocity advection of step k (ino:252-256) back-traces with the velocity step k - 1 left behind --
+//     the very field step k - 1's dye advection (ino:281-287) back-traced with, at the same dt.  Its reach has
+//     been measured by then: the halo of the velocity advection is EXACT, no guess;
+//   * the dye advection is the LAST operator of a step and writes into the other colour buffer.  It runs on a
+//     GUESSED halo (the reach known at the start of the step plus a margin); the kernel raises a flag when a
+//     back-trace leaves it, a small kernel measures the true reach of the projected velocity, both are reduced
+//     over the ranks on the exchange stream and copied to pinned host memory behind an event.  Whoever touches
+//     the context next (the next step, a download, sfl_synchronize) looks at the report first: flag down = done,
+//     reach recorded for the next step; flag up = the old colour buffer is still intact, the dye advection alone
+//     is repeated with the exact reach (or the gathered field).  Nothing downstream ever saw the wrong dye.
+static int ensure_report(sfl_context *c)
+{
+    if (c->d_report) return SFL_OK;
+    SFL_TRY(use_device(c));
+    void *d = nullptr, *h = nullptr;
+    HIP_TRY(hipMalloc(&d, 4 * sizeof(int)));
+    HIP_TRY(hipMemset(d, 0, 4 * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h, 4 * sizeof(int), hipHostMallocDefault));
+    memset(h, 0, 4 * sizeof(int));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_report, hipEventDisableTiming));
+    c->d_report = static_cast<int *>(d);
+    c->h_report = static_cast<int *>(h);
+    return SFL_OK;
+}
+
+// Measure the reach of the back-traces of the CURRENT velocity (the flag word of the report has been written by
+// the advection kernel before), reduce over the ranks, start the copy to the host.  No host wait.
+static int post_reach_report(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt)
+{
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(sfl::launch_backtrace_reach(c->stream, c->d_report, c->vel, c->geom, c->g0, c->g1, dt));
+    }
+    if (ctx->comm) {  // maximum over the ranks, on the exchange stream like every RCCL operation
+        Overlap o;
+        SFL_TRY(overlap_of(ctx, &o));
+        HIP_TRY(hipEventRecord(o.ready, o.compute));
+        HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
+        NCCL_TRY(ncclAllReduce(ctx->d_report, ctx->d_report, 4, ncclInt32, ncclMax, ctx->comm, o.xstream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_report, ctx->d_report, 4 * sizeof(int), hipMemcpyDeviceToHost, o.xstream));
+        HIP_TRY(hipEventRecord(ctx->ev_report, o.xstream));
+    } else {
+        for (sfl_context *c : peers) {
+            SFL_TRY(use_device(c));
+            HIP_TRY(hipMemcpyAsync(c->h_report, c->d_report, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_report, c->stream));
+        }
+    }
+    for (sfl_context *c : peers) {
+        c->color_unsettled = true;
+        c->unsettled_dt = dt;
+    }
+    return SFL_OK;
+}
+
+// Examine the report of the last dye advection that ran on a guessed halo (see above); repeat it when the guess
+// was short.  Cheap when nothing is pending.  Every entry point that reads or writes the fields calls it.
+static int settle_color(sfl_context *ctx)
+{
+    if (!ctx->color_unsettled) return SFL_OK;
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    int reach = 0, flag = 0;
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(hipEventSynchronize(c->ev_report));  // (the step it belongs to has long been queued; no stream is drained)
+        reach = std::max(reach, std::max(c->h_report[0], c->h_report[1]));
+        flag |= c->h_report[2];
+        c->color_unsettled = false;
+    }
+    const float dt = ctx->unsettled_dt;
+    for (sfl_context *c : peers) {  // the reach of the back-traces of the velocity as it stands now
+        c->known_reach = reach;
+        c->known_epoch = c->vel_epoch;
+        c->known_dt = dt;
+    }
+    if (!flag) return SFL_OK;
+    // the guess was short: back to the colour the step started with, advect again with what is now known
+    AdvectPlan plan;
+    plan.flag = false;
+    if (reach <= kGhostRows && reach <= min_owned_rows(ctx))
+        plan.halo = reach;
+    else
+        plan.gather = true;
+    for (sfl_context *c : peers) std::swap(c->col, c->col_tmp);
+    return advect_color_planned(ctx, peers, dt, 0, plan);
+}
+
+// One step of a slab group with the automatic advection halo (SFL_OPT_ADVECT_HALO = 0).
+static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float omega)
+{
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_report(c));
+        SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+        SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    }
+    const int limit = std::min(kGhostRows, min_owned_rows(ctx));
+    const bool known = ctx->known_reach >= 0 && ctx->known_epoch == ctx->vel_epoch && ctx->known_dt == dt;
+    int reach_v = 0;
+    if (known) {
+        reach_v = ctx->known_reach;
+    } else {  // first step, or the velocity was written from outside: one measured advection (a host round trip)
+        SFL_TRY(measure_reach(ctx, peers, dt, &reach_v));
+    }
+    AdvectPlan pv;
+    pv.flag = false;
+    if (reach_v <= limit)
+        pv.halo = reach_v;
+    else
+        pv.gather = true;
+    SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv));                // ino:252-256, exact halo
+    for (sfl_context *c : peers) SFL_TRY(apply_queued_forces(c));           // ino:264-269
+    SFL_TRY(sfl_calculate_divergence(ctx, dx));                             // ino:274
+    SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));                      // ino:275
+    // dye advection on a guessed halo: the projection changes the velocity a little, forces may change it a lot
+    const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(hipMemsetAsync(c->d_report, 0, 4 * sizeof(int), c->stream));
+    }
+    if (ctx->opt_fuse_projection) {
+        SFL_TRY(project_and_advect_color(ctx, dt, dx, guess, true));        // ino:276 + ino:281-287, one pass over v
+    } else {
+        SFL_TRY(sfl_subtract_gradient(ctx, dx));                            // ino:276
+        AdvectPlan pc;
+        pc.halo = guess;
+        pc.report = true;
+        SFL_TRY(advect_color_planned(ctx, peers, dt, 0, pc));               // ino:281-287
+    }
+    return post_reach_report(ctx, peers, dt);
+}
+
 int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     if (small_grid(ctx)) return small_grid_step(ctx, dt, dx, iters, omega);
+    if (ctx->nranks > 1 && ctx->opt_advect_halo == 0) return slab_step_auto(ctx, dt, dx, iters, omega);
     if (can_fuse_divergence(ctx)) {
         SFL_TRY(advect_velocity_and_divergence(ctx, dt, dx));  // ino:252-256 + ino:274
     } else {
@@ -1594,9 +1797,8 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
         SFL_TRY(sfl_calculate_divergence(ctx, dx));            // ino:274
     }
     SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));     // ino:275
-    // (slabs with the automatic advection halo measure the reach of the PROJECTED velocity first: two kernels)
-    if (ctx->opt_fuse_projection && !(ctx->nranks > 1 && ctx->opt_advect_halo == 0)) {
-        SFL_TRY(project_and_advect_color(ctx, dt, dx));    // ino:276 + ino:281-287, one pass over v
+    if (ctx->opt_fuse_projection) {
+        SFL_TRY(project_and_advect_color(ctx, dt, dx, ctx->opt_advect_halo, false));  // ino:276 + ino:281-287, one pass over v
     } else {
         SFL_TRY(sfl_subtract_gradient(ctx, dx));           // ino:276
         SFL_TRY(sfl_advect_color(ctx, dt, 0));             // ino:281-287
@@ -1646,6 +1848,7 @@ int sfl_render_rgb565(sfl_context *c, int scaling, int byteswap, uint16_t *host_
 int sfl_synchronize(sfl_context *ctx)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    SFL_TRY(settle_color(ctx));
     int rc = SFL_OK;
     for (sfl_context *c : peers_of(ctx)) {
         SFL_TRY(use_device(c));

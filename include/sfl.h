@@ -60,14 +60,19 @@ extern "C" {
                                      2 = fused multi-pass streaming kernel                       */
 #define SFL_OPT_SOR_FUSE 1        /* colour passes fused per launch by kernel 2: even, 2..16, or
                                      0 = auto (16 on slabs of >= 12 M cells, 10 from 3 M, else 8) */
-#define SFL_OPT_ADVECT_HALO 2     /* slabs: rows of the advected field exchanged per side.  1..64 =
-                                     fixed (default 4; a back-trace that leaves them is reported as
-                                     SFL_ERR_HALO by sfl_synchronize); 0 = automatic: the reach of
-                                     the back-traces is measured before every advection (a small
-                                     kernel + a 2-int all-reduce + one host round trip), exactly
-                                     that many rows are exchanged, and when it exceeds the 64
-                                     ghost rows the whole field is gathered on every GPU instead --
-                                     correct for any velocity                                     */
+#define SFL_OPT_ADVECT_HALO 2     /* slabs: rows of the advected field exchanged per side.  0 (default) =
+                                     automatic, correct for any velocity: sfl_step sizes the velocity
+                                     advection's halo from the reach measured at the end of the previous
+                                     step (the same velocity, the same dt: exact), runs the dye advection
+                                     on that reach plus a margin and checks it AFTER the step -- a flag and
+                                     the true reach travel to the host asynchronously and are examined by
+                                     the next call on the context, which repeats the dye advection alone
+                                     (from the untouched old buffer) if a back-trace left the guess; no
+                                     host round trip inside a step.  The stand-alone sfl_advect_* operators
+                                     and a step after the velocity was written from outside measure first
+                                     (one host round trip); beyond 64 rows the field is gathered on every
+                                     GPU.  1..64 = fixed: a back-trace that leaves them is reported as
+                                     SFL_ERR_HALO by sfl_synchronize                                      */
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
                                      1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link),

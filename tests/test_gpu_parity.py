@@ -173,6 +173,8 @@ def test_slab_advect_halo_overflow_is_reported(sfl):
     slabs = [sfl.Solver(dim_x, dim_y, 0, r, 2) for r in range(2)]
     try:
         sfl.Solver.link_group(slabs)
+        assert slabs[1].get_option(sfl.capi.OPT_ADVECT_HALO) == 0      # the default is the automatic halo
+        slabs[0].set_option(sfl.capi.OPT_ADVECT_HALO, 4)               # a FIXED halo reports what leaves it
         for s in slabs:
             s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
         slabs[0].advect_velocity(DT, True)
@@ -750,6 +752,57 @@ def test_automatic_advection_halo_and_gather_fallback(sfl, oracle, nranks, dim_y
     reach = abs(vy) + 1
     thinnest = dim_y // nranks
     assert (expect == "gather") == (reach > 64 or reach > thinnest)
+
+
+@pytest.mark.parametrize("nranks,fuse_projection", [(4, 1), (4, 0), (2, 1), (7, 1)])
+def test_slab_steps_on_the_automatic_halo_without_mid_step_round_trips(sfl, oracle, nranks, fuse_projection):
+    """SFL_OPT_ADVECT_HALO = 0 inside sfl_step (the default): from the second step on nothing is measured before an
+    advection -- the velocity advection takes the reach reported at the end of the previous step, the dye advection
+    runs on that reach plus a margin and is CHECKED afterwards, and repeated from the untouched old buffer when a
+    back-trace left the guess.  Six steps in a row against the oracle, every field after every step: a calm start,
+    then a drag force (ino:264-269) that throws a jet of 30 rows per step across a cut between advection and
+    projection (the guess of that step is short: the repeat path), the jet spreading in the following steps (reach
+    beyond the 64 ghost rows / the thinnest slab: the gathered path), an upload from outside in between."""
+    dim_x, dim_y, iters = 80, 224, 4
+    v, c, _ = random_fields(dim_x, dim_y, 77 + nranks, 45.0)         # |v dt| <= 1.5 rows
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    cut = slabs[1].row_begin
+    forces = {2: (np.array([[i, cut + 1] for i in range(20, 60)], np.int32),
+                  np.array([[0.0, 900.0]] * 40, np.float32)),          # 30 rows per step, upwards out of slab 1
+              4: (np.array([[7, 5]], np.int32), np.array([[30.0, -2400.0]], np.float32))}   # 80 rows per step
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_FUSE_PROJECTION, fuse_projection)
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        for k in range(6):
+            if k == 3:   # the velocity is replaced from outside: the reported reach no longer describes it
+                v = (v * np.float32(0.5)).astype(np.float32)
+                for s in slabs:
+                    s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            va = oracle.advect_vec2f(v, v, DT, True)
+            if k in forces:
+                cells, vel = forces[k]
+                slabs[0].queue_forces(cells, vel)
+                for (ci, cj), f in zip(cells, vel):
+                    va[cj, ci] = f
+            slabs[0].step(DT, 1.0, iters, OMEGA)
+            if k % 2:    # sometimes the next step settles the previous one, sometimes synchronize / download do
+                slabs[0].synchronize()
+            p = oracle.poisson_solve(oracle.divergence(va, 1.0), 1.0, iters, OMEGA)
+            v = oracle.subtract_gradient(va, p, 1.0)
+            c = oracle.advect_vec3uq32(c, v, DT, False)
+            if k in (1, 2, 4, 5):
+                assert_bit_equal(cat(sfl.capi.FIELD_COLOR), c, f"{nranks} slabs, step {k}: colour")
+                assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), v, f"{nranks} slabs, step {k}: velocity")
+        slabs[0].synchronize()
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), c, f"{nranks} slabs, final colour")
+        assert_bit_equal(cat(sfl.capi.FIELD_PRESSURE), p, f"{nranks} slabs, final pressure")
+    finally:
+        for s in slabs:
+            s.close()
 
 
 def _smooth_velocity(dim_x, dim_y, amp):
