@@ -61,6 +61,9 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #ifndef SFL_PRIO_LEVELS
 #define SFL_PRIO_LEVELS 4  // priority levels the waves of a SIMD rotate through (1 = leave the priority alone)
 #endif
+#ifndef SFL_PRIO_FORCE
+#define SFL_PRIO_FORCE (-1)  // diagnostic builds: 0 / 1 = rotation off / on whatever the launch; -1 = the launcher decides
+#endif
 #ifndef SFL_PRIO_ROWS
 #define SFL_PRIO_ROWS 2    // rows (pipeline iterations) a wave spends on one level; must divide 6
 #endif
@@ -100,7 +103,8 @@ struct WaveCommon {
     int grow0;           // global row of local row 0
     int row_lo, row_hi;  // global rows present in the local arrays AND inside the domain
     int row_sign;        // +1: pipeline row index = domain row; -1: its negative (tile streamed top-down)
-    int prio_turn;       // rotating issue priority: this wave's turn counter (see next_trip)
+    int prio_turn;       // rotating issue priority: this wave's turn counter (see next_turn)
+    int prio_on;         // ... enabled for this launch (wave-uniform)
 
     // the pipeline speaks in row INDICES t; domain row = row_sign * t (same parity either way)
     __device__ __forceinline__ sor::RowFacts row_facts(int t) const
@@ -119,6 +123,10 @@ struct WaveCommon {
     // wave therefore moves to the next priority level at each trip (its start level comes from its hardware
     // wave slot, so the waves of a SIMD start on different levels): over its life each wave spends the same
     // share of trips at each level, all advance at the same pace and the SIMD stays full to the end.
+    // Only for launches whose tiles are all resident at once (Tiling::rotate, set by the launcher): when tiles
+    // queue up behind the resident ones, a finished wave is replaced at once, the SIMDs stay full by themselves
+    // and the rotation only costs (16384^2, 2.3 rounds: 784 -> 804 us per launch with it; 8192^2, one round:
+    // 228 -> 217 us; profiles/r03_priority_rotation.txt).
     __device__ __forceinline__ void start_turns()
     {
         unsigned hw;
@@ -132,7 +140,9 @@ struct WaveCommon {
         // s_setprio takes an immediate: select it with scalar branches INSIDE one asm statement, so that the
         // straight-line trip stays straight-line for the compiler (a visible branch makes its wait-count pass
         // drain the loads in flight)
-        asm volatile("s_cmp_lg_u32 %0, 0\n\t"
+        asm volatile("s_cmp_eq_u32 %1, 0\n\t"
+                     "s_cbranch_scc1 .Lsfl_pe_%=\n\t"
+                     "s_cmp_lg_u32 %0, 0\n\t"
                      "s_cbranch_scc1 .Lsfl_p1_%=\n\t"
                      "s_setprio 0\n\t"
                      "s_branch .Lsfl_pe_%=\n"
@@ -150,7 +160,7 @@ struct WaveCommon {
                      "s_setprio 3\n"
                      ".Lsfl_pe_%=:"
                      :
-                     : "s"(prio_turn)
+                     : "s"(prio_turn), "s"(prio_on)
                      : "scc");
     }
     __device__ __forceinline__ int row_bytes(int t) const { return (row_sign * t - grow0) * dim_x * 4; }
@@ -350,6 +360,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.row_lo = max(g.grow0, 0);
         bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
         bk.row_sign = 1;
+        bk.prio_on = t.rotate;
         bk.start_turns();
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
         return bk;
@@ -466,9 +477,11 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
         return sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, g_begin, g_end, rpc,
                                 sor::kEdgeRowCost16, kFlipTiles ? 1 + (sweep & 1) : 0);
     };
-    const sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
+    sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
     const int tiles = t1.n_tiles + t2.n_tiles;
     if (tiles == 0) return hipSuccess;
+    // rotating issue priority (WaveCommon::next_turn) only when every tile is resident from the start
+    t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE : tiles <= resident_waves<B, NS, DX1, ZERO_IN>();
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm);
     return hipGetLastError();

@@ -338,6 +338,7 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
+    int rotate;           // the waves of a SIMD take turns at the top issue priority (GPU backend; set by the launcher)
     int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect):
                           // 1 = the odd chunks, 2 = the even ones, 0 = none
 };
@@ -375,6 +376,7 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
                           int g_end, int rows_per_chunk, int balance16, int flip = 0)
 {
     Tiling t;
+    t.rotate = 0;
     t.flip = flip;
     const int rows = g_end - g_begin;
     t.ns = ns;

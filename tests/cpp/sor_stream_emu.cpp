@@ -178,7 +178,7 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 template <int NS>
 int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
-               bool vec2, bool poison, bool force_edge, bool balance, bool flip, int *flipped_tiles)
+               bool vec2, bool poison, bool force_edge, bool balance, int flip, int *flipped_tiles)
 {
     using namespace sfl::sor;
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
@@ -243,7 +243,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
-                 bool vec2, bool poison, bool force_edge, bool balance, bool flip, int *flipped_tiles
+                 bool vec2, bool poison, bool force_edge, bool balance, int flip, int *flipped_tiles
 #define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
 #define EMU_DEFINE(N)                                                                             \
     int emu_run_ns##N(EMU_ARGS)                                                                   \
@@ -269,7 +269,8 @@ EMU_DEFINE(16)
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
 //        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
-//        bit4 = every second chunk of an inner strip is streamed top-down (the product's default)
+//        bit4 = every second chunk of an inner strip is streamed top-down (the product's default): the odd chunks,
+//        bit5 = ... the even chunks instead (the product's odd launches of a solve on big slabs)
 // returns the number of tiles streamed top-down (>= 0), or a negative error
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
@@ -277,7 +278,7 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
               int rows_per_chunk, int flags)
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
-    const bool flip = flags & 16;
+    const int flip = (flags & 32) ? 2 : (flags & 16) ? 1 : 0;
     int flipped_tiles = 0;
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \

@@ -35,7 +35,7 @@ def emu():
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (16 if flip else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (32 if flip == 2 else 16 if flip else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
         assert rc >= 0
@@ -153,3 +153,7 @@ def test_alternating_stream_direction(emu, oracle, ns, dim_x, dim_y, rows):
                      oracle.sor_iterate(p0, d, 0.5, ns // 2, np.float32(1.4)), "dx and omega")
     if dim_x > 300:
         assert flipped > 0, "no tile was streamed top-down"
+    # the odd launches of a solve on a big slab flip the EVEN chunks instead (successive launches alternate)
+    assert_bit_equal(emu(p0, d, ns, rows=rows, flip=2), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "even chunks flipped")
+    if dim_x > 300:
+        assert emu.flipped_tiles > 0
