@@ -77,6 +77,7 @@ SIGNATURES = {
     "sfl_device_info": (_i, [_i, C.c_char_p, _sz, _pi, C.POINTER(_sz)]),
     "sfl_slab_rows": (_i, [_i, _i, _i, _pi, _pi]),
     "sfl_plan_poisson": (_i, [_i, _i, _i, _i, _i, _i, _i, C.POINTER(PlanStep), _i, _pi]),
+    "sfl_plan_poisson_tail": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(PlanStep), _i, _pi]),
     "sfl_sor_pass_plan": (_i, [_i, _i, _pi, _pi, _i]),
     "sfl_host_advect_vec2f": (_i, [_pf, _pf, _pf, _i, _i, _f, _i]),
     "sfl_host_advect_vec3uq32": (_i, [_pu, _pu, _pf, _i, _i, _f, _i]),

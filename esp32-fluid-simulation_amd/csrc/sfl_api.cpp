@@ -134,12 +134,13 @@ struct sfl_context {
     // ... without a host round trip inside sfl_step (slab_step_auto): the dye advection runs on a GUESSED halo,
     // the true reach of its back-traces and an "a back-trace left the halo" flag are reduced on the device,
     // land in pinned host memory behind ev_report, and are examined when the NEXT call touches the context
-    int *d_report = nullptr;       // device {reach below, reach above, flag, 0}
+    int *d_report = nullptr;       // device reach words (launch_reach_set) with the flag in word [2]
     int *h_report = nullptr;       // pinned host copy
     hipEvent_t ev_report = nullptr;
     bool color_unsettled = false;  // a dye advection on a guessed halo has not been checked yet
     float unsettled_dt = 0.0f;
     int known_reach = -1;          // reach of the back-traces of the CURRENT velocity at known_dt (-1: unknown)
+    int known_reach_ext = -1;      // ... when own +- 1 rows are advected (reach_extended)
     uint64_t known_epoch = 0, vel_epoch = 1;   // vel_epoch counts the writes to the velocity field
     float known_dt = 0.0f;
 
@@ -153,6 +154,9 @@ struct sfl_context {
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
 
     int last_launches = 0, last_exchanges = 0, last_fuse = 0;
+    int solve_tail = 0;   // ghost rows of p the next solve must leave exact (slab_step_auto: 1, for subtract_gradient)
+    int p_ghost_valid = 0;  // ghost rows of p that are exact right now (set by the solve, cleared by whoever writes p)
+    int v_ghost_valid = 0;  // ghost rows of the velocity that are exact right now (slab_step_auto advects own +- 1 rows)
 
     size_t local_cells() const { return (size_t)geom.lrows * dim_x; }
     size_t owned_offset_cells() const { return (size_t)ghost * dim_x; }
@@ -650,8 +654,9 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
         progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel,
-                                          effective_halo(ctx, fuse)));
+                                          effective_halo(ctx, fuse), ctx->solve_tail));
         c->last_launches = c->last_exchanges = 0;
+        c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
     const sfl::SorParams prm = sor_params(dx, omega);
@@ -669,16 +674,28 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         }
         return SFL_OK;
     }
-    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && (ctx->comm || ctx->group || ctx->emulated))
-        return run_poisson_overlapped(ctx, peers, progs, prm);
-    for (size_t i = 0; i < progs[0].size(); ++i) {
-        const sfl_plan_step &st0 = progs[0][i];
-        if (st0.kind == SFL_STEP_EXCHANGE) {
-            SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
-        } else {
-            for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && (ctx->comm || ctx->group || ctx->emulated)) {
+        SFL_TRY(run_poisson_overlapped(ctx, peers, progs, prm));
+    } else {
+        for (size_t i = 0; i < progs[0].size(); ++i) {
+            const sfl_plan_step &st0 = progs[0][i];
+            if (st0.kind == SFL_STEP_EXCHANGE) {
+                SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
+            } else {
+                for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+            }
         }
     }
+    // ghost rows of p the last launch left exact (the plan's tail): what subtract_gradient may read without an exchange
+    int tail = ctx->nranks > 1 ? ctx->solve_tail : 0;
+    for (size_t k = 0; k < peers.size() && tail > 0; ++k) {
+        const sfl_context *c = peers[k];
+        const sfl_plan_step &last = progs[k].back();
+        if (last.kind != SFL_STEP_SOR) tail = 0;
+        if (c->rank > 0) tail = std::min(tail, c->g0 - last.g_begin);
+        if (c->rank < c->nranks - 1) tail = std::min(tail, last.g_end - c->g1);
+    }
+    for (sfl_context *c : peers) c->p_ghost_valid = tail > 0 ? tail : 0;
     return SFL_OK;
 }
 
@@ -838,6 +855,19 @@ int sfl_sor_pass_plan(int iters, int fuse, int *n_passes, int *passes, int cap)
     *n_passes = (int)v.size();
     if (passes)
         for (int k = 0; k < (int)v.size() && k < cap; ++k) passes[k] = v[k];
+    return SFL_OK;
+}
+
+int sfl_plan_poisson_tail(int dim_y, int nranks, int rank, int iters, int fuse, int kernel, int halo, int tail,
+                          sfl_plan_step *steps, int cap, int *n_steps)
+{
+    if (dim_y < 2 || nranks < 1 || rank < 0 || rank >= nranks || iters < 0 || !n_steps || halo < 0 || tail < 0 ||
+        (kernel != 1 && kernel != 2) || (kernel == 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
+        return fail(SFL_ERR_INVALID, "bad plan query");
+    const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, tail);
+    *n_steps = (int)v.size();
+    if (steps)
+        for (int k = 0; k < (int)v.size() && k < cap; ++k) steps[k] = v[k];
     return SFL_OK;
 }
 
@@ -1141,6 +1171,7 @@ int sfl_comm_loopback(sfl_context *c, int rows)
     NCCL_TRY(ncclGroupStart());
     NCCL_TRY(ncclSend(c->div + off, bytes, ncclChar, c->rank, c->comm, o.xstream));
     NCCL_TRY(ncclRecv(c->p + off, bytes, ncclChar, c->rank, c->comm, o.xstream));
+    c->p_ghost_valid = 0;
     NCCL_TRY(ncclGroupEnd());
     HIP_TRY(hipEventRecord(o.arrived, o.xstream));
     HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
@@ -1197,7 +1228,11 @@ int sfl_upload(sfl_context *c, int field, const void *host, size_t bytes)
     const size_t want = (size_t)(c->g1 - c->g0) * c->dim_x * eb;
     if (bytes != want) return fail(SFL_ERR_INVALID, "field %d: got %zu bytes, slab holds %zu", field, bytes, want);
     SFL_TRY(ensure_field(c, field));
-    if (field == SFL_FIELD_VELOCITY) ++c->vel_epoch;
+    if (field == SFL_FIELD_VELOCITY) {
+        ++c->vel_epoch;
+        c->v_ghost_valid = 0;
+    }
+    if (field == SFL_FIELD_PRESSURE) c->p_ghost_valid = 0;
     return upload_raw(c, field_ptr(c, field), host, eb);
 }
 
@@ -1250,36 +1285,57 @@ int *advect_flag(sfl_context *c, const AdvectPlan &plan)
     return plan.flag ? c->halo_flag : nullptr;
 }
 
-int measure_reach(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int *reach_out)
+// Reach words of a slab (device ints, atomicMax'ed by backtrace_reach_kernel; zero them first):
+//   [0] / [1]  rows the back-traces of the OWNED rows need below / above the slab;
+//   [5]        rows the back-traces of the slab's FIRST row need above it, [6] those of its LAST row below it --
+//              what the neighbour needs when it advects that row itself as a ghost row (slab_step_auto: the
+//              velocity advection covers own +- 1 rows); [4], [7] come with them and are covered by [0] / [1].
+constexpr int kReachWords = 8;
+int launch_reach_set(sfl_context *c, int *words, float dt)
 {
-    int reach = 0;
+    SFL_TRY(use_device(c));
+    HIP_TRY(sfl::launch_backtrace_reach(c->stream, words, c->vel, c->geom, c->g0, c->g1, dt));
+    HIP_TRY(sfl::launch_backtrace_reach(c->stream, words + 4, c->vel, c->geom, c->g0, std::min(c->g0 + 1, c->g1), dt));
+    HIP_TRY(sfl::launch_backtrace_reach(c->stream, words + 6, c->vel, c->geom, std::max(c->g1 - 1, c->g0), c->g1, dt));
+    return SFL_OK;
+}
+// halo that covers the owned rows' back-traces / those of own +- 1 rows (the neighbours' edge rows included)
+int reach_own(const int *w) { return std::max(w[0], w[1]); }
+int reach_extended(const int *w) { return std::max(reach_own(w), 1 + std::max(w[5], w[6])); }
+
+int measure_reach(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int *reach_out,
+                  int *reach_ext_out = nullptr)
+{
+    int reach = 0, reach_ext = 0;
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         if (!c->d_reach) {
             void *m = nullptr;
-            HIP_TRY(hipMalloc(&m, 2 * sizeof(int)));
+            HIP_TRY(hipMalloc(&m, kReachWords * sizeof(int)));
             c->d_reach = static_cast<int *>(m);
         }
-        HIP_TRY(hipMemsetAsync(c->d_reach, 0, 2 * sizeof(int), c->stream));
-        HIP_TRY(sfl::launch_backtrace_reach(c->stream, c->d_reach, c->vel, c->geom, c->g0, c->g1, dt));
+        HIP_TRY(hipMemsetAsync(c->d_reach, 0, kReachWords * sizeof(int), c->stream));
+        SFL_TRY(launch_reach_set(c, c->d_reach, dt));
     }
     if (ctx->comm) {  // maximum over the ranks, on the exchange stream like every RCCL operation
         Overlap o;
         SFL_TRY(overlap_of(ctx, &o));
         HIP_TRY(hipEventRecord(o.ready, o.compute));
         HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
-        NCCL_TRY(ncclAllReduce(ctx->d_reach, ctx->d_reach, 2, ncclInt32, ncclMax, ctx->comm, o.xstream));
+        NCCL_TRY(ncclAllReduce(ctx->d_reach, ctx->d_reach, kReachWords, ncclInt32, ncclMax, ctx->comm, o.xstream));
         HIP_TRY(hipEventRecord(o.arrived, o.xstream));
         HIP_TRY(hipStreamWaitEvent(o.compute, o.arrived, 0));
     }
     for (sfl_context *c : peers) {
-        int r[2] = {0, 0};
+        int r[kReachWords] = {0};
         SFL_TRY(use_device(c));
         HIP_TRY(hipMemcpyAsync(r, c->d_reach, sizeof r, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        reach = std::max(reach, std::max(r[0], r[1]));
+        reach = std::max(reach, reach_own(r));
+        reach_ext = std::max(reach_ext, reach_extended(r));
     }
     *reach_out = reach;
+    if (reach_ext_out) *reach_ext_out = reach_ext;
     return SFL_OK;
 }
 
@@ -1348,7 +1404,7 @@ int gather_field(sfl_context *ctx, const std::vector<sfl_context *> &peers, int 
 static int settle_color(sfl_context *ctx);
 
 static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
-                                   const AdvectPlan &plan);
+                                   const AdvectPlan &plan, int extend = 0);
 
 int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
 {
@@ -1364,8 +1420,10 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
     return advect_velocity_planned(ctx, peers, dt, no_slip, plan);
 }
 
+// `extend` = 1 (slab_step_auto; plan.halo then covers one row more than the reach): the ghost rows next to the cuts
+// are advected as well, redundantly -- calculate_divergence then needs no exchange of its own.
 static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
-                                   const AdvectPlan &plan)
+                                   const AdvectPlan &plan, int extend)
 {
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1383,11 +1441,13 @@ static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_conte
                                              c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
                                              nullptr, &whole, c->opt_advect_kernel));
         else
-            HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0, c->g1,
+            HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom,
+                                             clip_lo(c, c->g0 - extend), clip_hi(c, c->g1 + extend),
                                              clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
                                              no_slip != 0, advect_flag(c, plan), nullptr, c->opt_advect_kernel));
         std::swap(c->vel, c->vel_tmp);  // ino:255
         ++c->vel_epoch;
+        c->v_ghost_valid = plan.gather ? 0 : extend;
     }
     return SFL_OK;
 }
@@ -1447,7 +1507,7 @@ int sfl_calculate_divergence(sfl_context *ctx, float dx)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
     }
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, 1));
+    if (ctx->v_ghost_valid < 1) SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, 1));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
@@ -1473,13 +1533,14 @@ int sfl_subtract_gradient(sfl_context *ctx, float dx)
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
     }
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
+    if (ctx->p_ghost_valid < 1) SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(sfl::launch_subtract_gradient(c->stream, c->vel, c->p, c->geom, c->g0, c->g1,
                                               two_dx_inv, c->opt_advect_kernel));
         ++c->vel_epoch;
+        c->v_ghost_valid = 0;
     }
     return SFL_OK;
 }
@@ -1556,9 +1617,9 @@ static int apply_queued_forces(sfl_context *c)
 {
     int n = 0;
     SFL_TRY(stage_queued_forces(c, &n));
-    if (n > 0) {
-        HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, c->g0, c->g1, c->d_force_cells,
-                                         c->d_force_vel, n));
+    if (n > 0) {  // (the exact ghost rows, if any, receive the forces that fall into them as well)
+        HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, clip_lo(c, c->g0 - c->v_ghost_valid),
+                                         clip_hi(c, c->g1 + c->v_ghost_valid), c->d_force_cells, c->d_force_vel, n));
         ++c->vel_epoch;
     }
     return SFL_OK;
@@ -1575,7 +1636,7 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int ha
         SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
+    if (ctx->p_ghost_valid < 1) SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
     SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, halo));
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
@@ -1587,6 +1648,7 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int ha
             two_dx_inv, c->opt_advect_kernel));
         std::swap(c->col, c->col_tmp);  // ino:286
         ++c->vel_epoch;                 // the projection rewrote the velocity
+        c->v_ghost_valid = 0;
     }
     return SFL_OK;
 }
@@ -1666,10 +1728,10 @@ static int ensure_report(sfl_context *c)
     if (c->d_report) return SFL_OK;
     SFL_TRY(use_device(c));
     void *d = nullptr, *h = nullptr;
-    HIP_TRY(hipMalloc(&d, 4 * sizeof(int)));
-    HIP_TRY(hipMemset(d, 0, 4 * sizeof(int)));
-    HIP_TRY(hipHostMalloc(&h, 4 * sizeof(int), hipHostMallocDefault));
-    memset(h, 0, 4 * sizeof(int));
+    HIP_TRY(hipMalloc(&d, kReachWords * sizeof(int)));
+    HIP_TRY(hipMemset(d, 0, kReachWords * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h, kReachWords * sizeof(int), hipHostMallocDefault));
+    memset(h, 0, kReachWords * sizeof(int));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_report, hipEventDisableTiming));
     c->d_report = static_cast<int *>(d);
     c->h_report = static_cast<int *>(h);
@@ -1680,22 +1742,19 @@ static int ensure_report(sfl_context *c)
 // the advection kernel before), reduce over the ranks, start the copy to the host.  No host wait.
 static int post_reach_report(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt)
 {
-    for (sfl_context *c : peers) {
-        SFL_TRY(use_device(c));
-        HIP_TRY(sfl::launch_backtrace_reach(c->stream, c->d_report, c->vel, c->geom, c->g0, c->g1, dt));
-    }
+    for (sfl_context *c : peers) SFL_TRY(launch_reach_set(c, c->d_report, dt));
     if (ctx->comm) {  // maximum over the ranks, on the exchange stream like every RCCL operation
         Overlap o;
         SFL_TRY(overlap_of(ctx, &o));
         HIP_TRY(hipEventRecord(o.ready, o.compute));
         HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
-        NCCL_TRY(ncclAllReduce(ctx->d_report, ctx->d_report, 4, ncclInt32, ncclMax, ctx->comm, o.xstream));
-        HIP_TRY(hipMemcpyAsync(ctx->h_report, ctx->d_report, 4 * sizeof(int), hipMemcpyDeviceToHost, o.xstream));
+        NCCL_TRY(ncclAllReduce(ctx->d_report, ctx->d_report, kReachWords, ncclInt32, ncclMax, ctx->comm, o.xstream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_report, ctx->d_report, kReachWords * sizeof(int), hipMemcpyDeviceToHost, o.xstream));
         HIP_TRY(hipEventRecord(ctx->ev_report, o.xstream));
     } else {
         for (sfl_context *c : peers) {
             SFL_TRY(use_device(c));
-            HIP_TRY(hipMemcpyAsync(c->h_report, c->d_report, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->h_report, c->d_report, kReachWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->ev_report, c->stream));
         }
     }
@@ -1712,17 +1771,19 @@ static int settle_color(sfl_context *ctx)
 {
     if (!ctx->color_unsettled) return SFL_OK;
     std::vector<sfl_context *> peers = peers_of(ctx);
-    int reach = 0, flag = 0;
+    int reach = 0, reach_ext = 0, flag = 0;
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipEventSynchronize(c->ev_report));  // (the step it belongs to has long been queued; no stream is drained)
-        reach = std::max(reach, std::max(c->h_report[0], c->h_report[1]));
+        reach = std::max(reach, reach_own(c->h_report));
+        reach_ext = std::max(reach_ext, reach_extended(c->h_report));
         flag |= c->h_report[2];
         c->color_unsettled = false;
     }
     const float dt = ctx->unsettled_dt;
     for (sfl_context *c : peers) {  // the reach of the back-traces of the velocity as it stands now
         c->known_reach = reach;
+        c->known_reach_ext = reach_ext;
         c->known_epoch = c->vel_epoch;
         c->known_dt = dt;
     }
@@ -1749,27 +1810,40 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     }
     const int limit = std::min(kGhostRows, min_owned_rows(ctx));
     const bool known = ctx->known_reach >= 0 && ctx->known_epoch == ctx->vel_epoch && ctx->known_dt == dt;
-    int reach_v = 0;
+    int reach_v = 0, reach_v_ext = 0;  // halo for the owned rows' back-traces / for those of own +- 1 rows
     if (known) {
         reach_v = ctx->known_reach;
+        reach_v_ext = ctx->known_reach_ext;
     } else {  // first step, or the velocity was written from outside: one measured advection (a host round trip)
-        SFL_TRY(measure_reach(ctx, peers, dt, &reach_v));
+        SFL_TRY(measure_reach(ctx, peers, dt, &reach_v, &reach_v_ext));
     }
+    // Two of the step's small exchanges are traded for one redundant row each: the velocity advection also advects
+    // the ghost row next to each cut (halo = reach_extended: the neighbours' edge rows trace into THEIR slabs), so calculate_divergence finds
+    // its neighbours' rows in place; and the solve leaves one ghost row of p exact (plan tail), which is all
+    // subtract_gradient reads beyond the cut.
     AdvectPlan pv;
     pv.flag = false;
-    if (reach_v <= limit)
+    int extend = 0;
+    if (reach_v_ext <= limit) {
+        pv.halo = std::max(reach_v_ext, 1);
+        extend = 1;
+    } else if (reach_v <= limit) {
         pv.halo = reach_v;
-    else
+    } else {
         pv.gather = true;
-    SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv));                // ino:252-256, exact halo
+    }
+    SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv, extend));        // ino:252-256, exact halo
     for (sfl_context *c : peers) SFL_TRY(apply_queued_forces(c));           // ino:264-269
     SFL_TRY(sfl_calculate_divergence(ctx, dx));                             // ino:274
-    SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));                      // ino:275
+    for (sfl_context *c : peers) c->solve_tail = 1;
+    const int rc_solve = sfl_poisson_solve(ctx, dx, iters, omega);          // ino:275
+    for (sfl_context *c : peers) c->solve_tail = 0;
+    SFL_TRY(rc_solve);
     // dye advection on a guessed halo: the projection changes the velocity a little, forces may change it a lot
     const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
-        HIP_TRY(hipMemsetAsync(c->d_report, 0, 4 * sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_report, 0, kReachWords * sizeof(int), c->stream));
     }
     if (ctx->opt_fuse_projection) {
         SFL_TRY(project_and_advect_color(ctx, dt, dx, guess, true));        // ino:276 + ino:281-287, one pass over v

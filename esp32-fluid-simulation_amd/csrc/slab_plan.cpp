@@ -26,7 +26,7 @@ static sfl_plan_step exchange(int field, int rows, int skip = 0)
 }
 
 std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse,
-                                        int kernel, int halo)
+                                        int kernel, int halo, int tail)
 {
     std::vector<sfl_plan_step> prog;
     int g0, g1;
@@ -63,6 +63,7 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
     const std::vector<int> passes = sor_pass_plan(iters, fuse);
     if (halo < fuse) halo = fuse;
 
+    if (tail < 0 || !(multi && halo >= 2 * fuse + tail)) tail = 0;  // (only the early-exchange plan carries a tail)
     if (multi && halo >= 2 * fuse) {
         // EARLY exchanges (halo of at least two launches).  A launch needs `nsweeps` valid ghost rows to produce
         // its own rows; everything deeper only feeds later launches.  So the halo for the next group of launches
@@ -78,23 +79,26 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
         // extra[j] = ghost rows that must still be valid after launch j = passes of the launches up to and
         // including the next exchange launch (whose owned rows are produced from what is there)
         std::vector<int> xchg_before(n, 0), extra(n, 0);
-        int budget = halo;
+        int budget = halo - tail;
         for (size_t j = 0; j < n; ++j) {
             if (passes[j] > budget) {  // launch j does not fit what is left: the exchange goes before launch j - 1
                 xchg_before[j - 1] = 1;
-                budget = halo - passes[j - 1];
+                budget = halo - tail - passes[j - 1];
             }
             budget -= passes[j];
         }
+        extra[n - 1] = tail;
         for (size_t j = n; j-- > 0;) {
             // rows needed after launch j: the following launches up to and including the next exchange launch
-            if (j + 1 < n) extra[j] = xchg_before[j + 1] ? passes[j + 1] : extra[j + 1] + passes[j + 1];
+            // (whose owned rows + tail come from what is there: the exchange skips passes + tail rows)
+            if (j + 1 < n) extra[j] = xchg_before[j + 1] ? passes[j + 1] + tail : extra[j + 1] + passes[j + 1];
         }
         int deepest = 0;  // pass 1 of launch j relaxes its output rows +- (n_j - 1): rows of the right-hand side
         for (size_t j = 0; j < n; ++j) deepest = extra[j] + passes[j] > deepest ? extra[j] + passes[j] : deepest;
         if (deepest > 1) prog.push_back(exchange(SFL_FIELD_DIVERGENCE, deepest - 1));
         for (size_t j = 0; j < n; ++j) {
-            if (xchg_before[j]) prog.push_back(exchange(SFL_FIELD_PRESSURE, halo - passes[j], passes[j]));
+            if (xchg_before[j])
+                prog.push_back(exchange(SFL_FIELD_PRESSURE, halo - passes[j] - tail, passes[j] + tail));
             sfl_plan_step c{};
             c.kind = SFL_STEP_SOR;
             c.g_begin = g0 - extra[j] < 0 ? 0 : g0 - extra[j];

@@ -24,7 +24,10 @@ std::vector<int> sor_pass_plan(int iters, int fuse);
 // Program of one poisson_solve for one rank; every rank's program has the same length and the
 // same kinds at the same positions (exchanges are matched pairs).
 // halo = rows of p exchanged per superstep (>= fuse; kernel 2 only)
+// tail = ghost rows that must still be exact when the solve ends (early exchanges only: every launch then extends
+// `tail` rows further into the ghost rows; sfl_step on slabs asks for 1 -- the row subtract_gradient reads --
+// and saves the 1-row exchange of p after the solve)
 std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse,
-                                        int kernel, int halo);
+                                        int kernel, int halo, int tail = 0);
 
 }  // namespace sfl

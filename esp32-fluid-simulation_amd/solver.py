@@ -54,15 +54,16 @@ def sor_pass_plan(iters: int, fuse: int):
 
 
 def plan_poisson(dim_y: int, nranks: int, rank: int, iters: int, fuse: int = 8, kernel: int = 2,
-                 halo: int = 0):
+                 halo: int = 0, tail: int = 0):
     """The launch / halo-exchange program of one poisson_solve for one rank (pure arithmetic).
-    halo = rows of p exchanged per superstep (0: exchange before every launch)."""
+    halo = rows of p exchanged per superstep (0: exchange before every launch); tail = ghost rows of p left
+    exact at the end (early-exchange plans only)."""
     n = C.c_int()
-    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, None, 0,
-                                           C.byref(n)))
+    capi.check(capi.lib().sfl_plan_poisson_tail(dim_y, nranks, rank, iters, fuse, kernel, halo, tail, None, 0,
+                                                C.byref(n)))
     steps = (capi.PlanStep * max(n.value, 1))()
-    capi.check(capi.lib().sfl_plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, steps,
-                                           n.value, C.byref(n)))
+    capi.check(capi.lib().sfl_plan_poisson_tail(dim_y, nranks, rank, iters, fuse, kernel, halo, tail, steps,
+                                                n.value, C.byref(n)))
     return [steps[k] for k in range(n.value)]
 
 

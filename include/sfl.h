@@ -163,6 +163,12 @@ typedef struct sfl_plan_step {
  * the GPU executor walks exactly this program.                                               */
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
                              int halo, sfl_plan_step *steps, int cap, int *n_steps);
+/* The same with a TAIL: `tail` ghost rows of p are still exact when the solve ends (every launch of an
+ * early-exchange plan then extends that much further into the ghost rows; ignored -- as 0 -- by the other
+ * plans).  sfl_step on slabs asks for 1, the row subtract_gradient (finitediff.cpp:41-82) reads beyond a
+ * cut, and so needs no exchange of p between the solve and the projection.                          */
+SFL_API int sfl_plan_poisson_tail(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
+                                  int halo, int tail, sfl_plan_step *steps, int cap, int *n_steps);
 
 /* Pass plan of one poisson_solve: 2*iters half-sweeps are executed as `*n_passes` launches of
  * at most `fuse` half-sweeps each (the last one may be shorter); passes[k] receives the

@@ -754,17 +754,21 @@ def test_automatic_advection_halo_and_gather_fallback(sfl, oracle, nranks, dim_y
     assert (expect == "gather") == (reach > 64 or reach > thinnest)
 
 
-@pytest.mark.parametrize("nranks,fuse_projection", [(4, 1), (4, 0), (2, 1), (7, 1)])
-def test_slab_steps_on_the_automatic_halo_without_mid_step_round_trips(sfl, oracle, nranks, fuse_projection):
+@pytest.mark.parametrize("nranks,fuse_projection,vamp", [(4, 1, 45.0), (4, 0, 45.0), (2, 1, 45.0), (7, 1, 45.0), (3, 1, 400.0),
+                                                         (4, 1, 900.0)])
+def test_slab_steps_on_the_automatic_halo_without_mid_step_round_trips(sfl, oracle, nranks, fuse_projection, vamp):
     """SFL_OPT_ADVECT_HALO = 0 inside sfl_step (the default): from the second step on nothing is measured before an
     advection -- the velocity advection takes the reach reported at the end of the previous step, the dye advection
     runs on that reach plus a margin and is CHECKED afterwards, and repeated from the untouched old buffer when a
     back-trace left the guess.  Six steps in a row against the oracle, every field after every step: a calm start,
     then a drag force (ino:264-269) that throws a jet of 30 rows per step across a cut between advection and
     projection (the guess of that step is short: the repeat path), the jet spreading in the following steps (reach
-    beyond the 64 ghost rows / the thinnest slab: the gathered path), an upload from outside in between."""
+    beyond the 64 ghost rows / the thinnest slab: the gathered path), an upload from outside in between.
+    The velocity advection also covers the ghost row next to each cut (calculate_divergence then exchanges nothing):
+    with per-cell noise of 13 or 30 rows per step (vamp 400 / 900) the neighbour's edge row traces deep into the
+    neighbour's own slab, which the halo has to cover (reach_extended)."""
     dim_x, dim_y, iters = 80, 224, 4
-    v, c, _ = random_fields(dim_x, dim_y, 77 + nranks, 45.0)         # |v dt| <= 1.5 rows
+    v, c, _ = random_fields(dim_x, dim_y, 77 + nranks, vamp)         # |v dt| <= 1.5 rows at vamp 45
     slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
     cut = slabs[1].row_begin
     forces = {2: (np.array([[i, cut + 1] for i in range(20, 60)], np.int32),
