@@ -137,6 +137,7 @@ struct sfl_context {
     int *d_report = nullptr;       // device reach words (launch_reach_set) with the flag in word [2]
     int *h_report = nullptr;       // pinned host copy
     hipEvent_t ev_report = nullptr;
+    hipEvent_t ev_color_halo = nullptr;  // the dye's halo, sent at the START of a step (slab_step_auto), has arrived
     bool color_unsettled = false;  // a dye advection on a guessed halo has not been checked yet
     float unsettled_dt = 0.0f;
     int known_reach = -1;          // reach of the back-traces of the CURRENT velocity at known_dt (-1: unknown)
@@ -967,6 +968,7 @@ int sfl_destroy(sfl_context *c)
     if (c->d_report) (void)hipFree(c->d_report);
     if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->ev_report) (void)hipEventDestroy(c->ev_report);
+    if (c->ev_color_halo) (void)hipEventDestroy(c->ev_color_halo);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_arrived) (void)hipEventDestroy(c->ev_arrived);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1276,6 +1278,7 @@ struct AdvectPlan {
     bool flag = true;     // fixed halo: let the kernel report a back-trace that leaves it
     bool report = false;  // ... into the context's reach report (a guessed halo, checked by settle_color)
                           // instead of the error flag sfl_synchronize turns into SFL_ERR_HALO
+    bool halo_sent = false;  // the halo rows are already on their way (behind ev_color_halo): wait, do not exchange
 };
 
 int *advect_flag(sfl_context *c, const AdvectPlan &plan)
@@ -1478,10 +1481,14 @@ static int advect_color_planned(sfl_context *ctx, const std::vector<sfl_context 
         SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
-    if (plan.gather)
+    if (plan.gather) {
         SFL_TRY(gather_field(ctx, peers, SFL_FIELD_COLOR));
-    else
+    } else if (plan.halo_sent) {
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_color_halo, 0));
+    } else {
         SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, plan.halo));
+    }
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         const sfl::Slab whole{c->dim_x, c->gdim_y, 0, c->gdim_y};
@@ -1627,7 +1634,9 @@ static int apply_queued_forces(sfl_context *c)
 
 
 // ino:276 + ino:281-287 in one pass: project each cell's own velocity, advect the dye with it.
-static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int halo, bool report)
+// halo_sent: the dye's halo is already on its way / there (slab_step_auto sends it at the start of the step, behind
+// ev_color_halo): wait for it instead of exchanging
+static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int halo, bool report, bool halo_sent = false)
 {
     std::vector<sfl_context *> peers = peers_of(ctx);
     for (sfl_context *c : peers) {
@@ -1637,7 +1646,12 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int ha
         SFL_TRY(ensure(c, c->col_tmp, 12, false));
     }
     if (ctx->p_ghost_valid < 1) SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_PRESSURE, 1));
-    SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, halo));
+    if (halo_sent) {
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_color_halo, 0));
+    } else {
+        SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_COLOR, halo));
+    }
     const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:78-79
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
@@ -1733,6 +1747,7 @@ static int ensure_report(sfl_context *c)
     HIP_TRY(hipHostMalloc(&h, kReachWords * sizeof(int), hipHostMallocDefault));
     memset(h, 0, kReachWords * sizeof(int));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_report, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_color_halo, hipEventDisableTiming));
     c->d_report = static_cast<int *>(d);
     c->h_report = static_cast<int *>(h);
     return SFL_OK;
@@ -1817,6 +1832,21 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     } else {  // first step, or the velocity was written from outside: one measured advection (a host round trip)
         SFL_TRY(measure_reach(ctx, peers, dt, &reach_v, &reach_v_ext));
     }
+    // The dye is not touched before the end of the step and its halo is a guess made from what is known NOW (the
+    // projection changes the velocity a little, forces may change it a lot: checked after the step): send it at
+    // once, on the exchange stream, under the velocity advection and the solve.
+    const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
+    {
+        for (sfl_context *c : peers) {
+            SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+            SFL_TRY(ensure(c, c->col_tmp, 12, false));
+        }
+        Overlap o;
+        SFL_TRY(overlap_of(ctx, &o));
+        SFL_TRY(start_exchange(peers, o, SFL_FIELD_COLOR, guess, 0, false));
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(hipEventRecord(ctx->ev_color_halo, o.xstream));
+    }
     // Two of the step's small exchanges are traded for one redundant row each: the velocity advection also advects
     // the ghost row next to each cut (halo = reach_extended: the neighbours' edge rows trace into THEIR slabs), so calculate_divergence finds
     // its neighbours' rows in place; and the solve leaves one ghost row of p exact (plan tail), which is all
@@ -1839,19 +1869,19 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     const int rc_solve = sfl_poisson_solve(ctx, dx, iters, omega);          // ino:275
     for (sfl_context *c : peers) c->solve_tail = 0;
     SFL_TRY(rc_solve);
-    // dye advection on a guessed halo: the projection changes the velocity a little, forces may change it a lot
-    const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
+    // dye advection on the guessed halo sent at the start of the step
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipMemsetAsync(c->d_report, 0, kReachWords * sizeof(int), c->stream));
     }
     if (ctx->opt_fuse_projection) {
-        SFL_TRY(project_and_advect_color(ctx, dt, dx, guess, true));        // ino:276 + ino:281-287, one pass over v
+        SFL_TRY(project_and_advect_color(ctx, dt, dx, guess, true, true));  // ino:276 + ino:281-287, one pass over v
     } else {
         SFL_TRY(sfl_subtract_gradient(ctx, dx));                            // ino:276
         AdvectPlan pc;
         pc.halo = guess;
         pc.report = true;
+        pc.halo_sent = true;
         SFL_TRY(advect_color_planned(ctx, peers, dt, 0, pc));               // ino:281-287
     }
     return post_reach_report(ctx, peers, dt);
