@@ -734,10 +734,13 @@ int default_device()
 // on a 61 x 81 grid (ino:252-287): creating stream, events and buffers anew for each of them cost
 // 3.2 ms per frame (profiles/r01_host_dropin_pcie.txt), ten times the reference's CPU time.  So
 // the context of the last call stays with the calling thread -- for grids of up to
-// kHostCacheCells cells only (<= 140 MB of fields; above that the set-up is noise next to the PCIe
-// transfers and nothing is retained) -- until the shape changes, a call fails, or
-// sfl_host_release() is called.
-constexpr int64_t kHostCacheCells = 1 << 22;
+// kHostCacheCells cells (2^26 = 8192^2: at most 3.25 GB of fields on a 288 GB part) -- until the shape
+// changes, a call fails, or sfl_host_release() is called.  At 8192^2 the set-up (768 MB of hipMalloc + fill,
+// stream, events, hipFree) is 4 of the 15.6 ms a poisson_solve drop-in takes; the two 256 MB transfers already run
+// at the PCIe rate from pageable memory (4.75 + 4.8 ms: the runtime pins the caller's pages after their first use,
+// tools/ubench_host_register.hip), the solve takes 1.8 ms: 11.4 ms with the context retained
+// (profiles/r03_host_dropin.txt).
+constexpr int64_t kHostCacheCells = 1 << 26;
 thread_local sfl_context *g_host_cached = nullptr;
 
 struct HostCtx {

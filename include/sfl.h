@@ -200,7 +200,7 @@ SFL_API int sfl_host_subtract_gradient(float *v, const float *p, int dim_x, int 
 SFL_API int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, float dx,
                                    int iters, float omega);
 /* The operators above never retain caller pointers (as the reference: finitediff.cpp:36,78-79,
- * poisson.cpp:120 keep their contexts on the stack).  For grids of up to 2^22 cells they do keep
+ * poisson.cpp:120 keep their contexts on the stack).  For grids of up to 2^26 cells (8192^2) they do keep
  * their device-side working context with the calling thread between calls, so that a loop() of
  * five operators per frame (ino:252-287) does not set up streams and buffers five times per
  * frame; this releases it (optional; also replaced whenever the grid shape changes).          */
