@@ -1049,3 +1049,41 @@ def test_small_grid_limit_and_explicit_options(sfl, oracle):
         s.synchronize()
         assert s.last_solve_info()["launches"] == 3
         assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.poisson_solve(d, 1.0, 12, OMEGA), "explicit fuse")
+
+
+def test_emulated_rank_runs_its_program_alone(sfl):
+    """sfl_comm_emulate (bench.py --emulate-rank): ONE rank of an 8-slab solve alone on the GPU, every halo message a
+    self-copy of the same size on the exchange stream.  Values next to the cuts are meaningless by construction, but
+    the program is the rank's own: launch / exchange counts equal the plan's, rows further than the solve's reach
+    from the cuts equal the whole-domain result bit for bit, and a whole step runs through (automatic advection
+    halo, report, settle) without error."""
+    dim_x, dim_y, nranks, rank, iters = 640, 2048, 8, 3, 12
+    import bench
+    v = bench.synthetic_velocity(dim_x, 0, dim_y)
+    with sfl.Solver(dim_x, dim_y) as one:
+        one.upload(sfl.capi.FIELD_VELOCITY, v)
+        one.calculate_divergence(1.0)
+        one.poisson_solve(1.0, iters, OMEGA)
+        one.synchronize()
+        d, want = one.download(sfl.capi.FIELD_DIVERGENCE), one.download(sfl.capi.FIELD_PRESSURE)
+    with sfl.Solver(dim_x, dim_y, 0, rank, nranks) as s:
+        with pytest.raises(sfl.SflError):
+            s.poisson_solve(1.0, iters, OMEGA)          # a slab without a transport cannot exchange
+    with sfl.Solver(dim_x, dim_y, 0, rank, nranks) as s:
+        s.comm_emulate()
+        assert s.get_option(sfl.capi.OPT_TRANSPORT) == 3
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        s.poisson_solve(1.0, iters, OMEGA)
+        s.synchronize()
+        info = s.last_solve_info()
+        got = s.download(sfl.capi.FIELD_PRESSURE)
+        assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, info["fuse"]) and info["launches"] == -(-2 * iters // info["fuse"])
+        # information travels one row per colour pass: 2 * iters rows from each cut are tainted by the fake halos
+        reach = 2 * iters
+        inner = slice(reach, (s.row_end - s.row_begin) - reach)
+        assert_bit_equal(got[inner], want[s.row_begin:s.row_end][inner], "emulated rank: rows out of the cuts' reach")
+        s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+        s.upload(sfl.capi.FIELD_COLOR, bench.synthetic_color(dim_x, s.row_begin, s.row_end))
+        for _ in range(3):
+            s.step(DT, 1.0, iters, OMEGA)
+        s.synchronize()
