@@ -79,17 +79,20 @@ extern "C" {
                                      3 = emulated (sfl_comm_emulate: timing only)                 */
 #define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto or 2 (the only flavour
                                      left: round 1's packed 4-cell tiles were never faster)        */
-#define SFL_OPT_SOR_HALO 6        /* rows of p exchanged per superstep on a slab (kernel 2): 0 =
+#define SFL_OPT_SOR_HALO 6        /* rows of p a superstep's halo makes valid on a slab (kernel 2): 0 =
                                      auto (64 on slabs of >= 1024 rows, else 32), else fuse..64;
-                                     larger = fewer, larger exchanges, more recomputed ghost rows */
+                                     larger = fewer, larger exchanges, more recomputed ghost rows; from
+                                     2 x fuse on the exchanges are issued one launch early (sfl_plan_poisson) */
 #define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied
                                      inside the dye-advection kernel (one pass over v), 0 = two
                                      kernels                                                     */
 
-#define SFL_OPT_SOR_OVERLAP 8     /* slabs, kernel 2: 1 (default) = the halo exchanges of a solve run
-                                     on a second stream, overlapped with the rows of the
-                                     neighbouring launches that do not depend on them (cut-adjacent
-                                     rows first / last); 0 = every launch whole, exchanges in line */
+#define SFL_OPT_SOR_OVERLAP 8     /* slabs, kernel 2: 1 (default) = the halo exchanges of a solve run on a
+                                     second stream: a superstep's halo travels one launch early while the
+                                     owned rows of that launch are relaxed, its ghost rows are relaxed behind
+                                     the message (halo >= 2 x fuse; otherwise, and for the right-hand side:
+                                     cut-adjacent rows first / last around the message);
+                                     0 = every launch whole, exchanges in line                          */
 #define SFL_OPT_ADVECT_KERNEL 9   /* advection, divergence and gradient kernels: 0 = auto, 1 = one
                                      thread per cell reading its neighbours / texels from memory,
                                      2 = the window of a 64 x 32-cell tile staged in LDS (auto = 2
