@@ -179,6 +179,34 @@ int main(int argc, char **argv)
         for (double x : life_us) sum += x;
         printf("mean waves alive over the span: %.1f (of %zu)\n", sum / ((double)(wlast - wbase) * 0.01), n);
     }
+    {   // the slowest waves and what they were streaming (the tiling the launcher chose, recomputed here)
+        using B = sfl::Lane2<PROBE_NS, true, false, false>;
+        const int waves = sfl::resident_waves<B, PROBE_NS, true, false>();
+        const int use_rpc = rpc > 0 ? rpc : sfl::auto_rows_per_chunk<B>(g, 0, dim_y, PROBE_NS, waves, sfl::device_simds());
+        const sfl::sor::Tiling t = sfl::sor::make_tiling(PROBE_NS, B::kTileCols, B::kColAlign, dim_x, dim_y, 0, dim_y, use_rpc,
+                                                         sfl::sor::kEdgeRowCost16, 1);
+        printf("tiling: rows per tile %d (boundary strips %d, first / last chunk %d / %d), %d strips (%d inner), %d tiles\n",
+               t.rows_per_chunk, t.rows_edge, t.rows_first, t.rows_last, t.n_strips, t.n_inner, t.n_tiles);
+        std::vector<std::pair<double, size_t>> order;
+        for (size_t k = 0; k < n; ++k) order.push_back({end_us[k], k});
+        std::sort(order.rbegin(), order.rend());
+        for (int k = 0; k < 12 && k < (int)order.size(); ++k) {
+            const size_t tile = order[k].second;
+            const sfl::sor::TileRect r = sfl::sor::tile_rect(t, (int)tile);
+            printf("  end %.1f us  life %.1f us  tile %zu kind %llu  strip %d rows [%d, %d) = %d\n", order[k].first, life_us[tile], tile,
+                   h[6 * tile + 5] >> 32, r.strip, r.r0, r.r1, r.r1 - r.r0);
+        }
+        // by class: inner strips' first / last chunk, boundary strips, the rest
+        double worst[4] = {0, 0, 0, 0};
+        const char *cls[4] = {"interior", "inner strip, first chunk", "inner strip, last chunk", "boundary strip"};
+        for (size_t k = 0; k < n; ++k) {
+            const sfl::sor::TileRect r = sfl::sor::tile_rect(t, (int)k);
+            const bool inner = (int)k < t.n_inner * t.n_chunks;
+            const int c = !inner ? 3 : (r.r0 == 0 ? 1 : (r.r1 == dim_y ? 2 : 0));
+            worst[c] = std::max(worst[c], end_us[k]);
+        }
+        for (int c = 0; c < 4; ++c) printf("  last wave of class '%s' ends at %.1f us\n", cls[c], worst[c]);
+    }
     if (csv) {
         FILE *f = fopen(csv, "w");
         if (f) {
