@@ -1627,7 +1627,8 @@ static int apply_queued_forces(sfl_context *c)
 {
     int n = 0;
     SFL_TRY(stage_queued_forces(c, &n));
-    if (n > 0) {  // (the exact ghost rows, if any, receive the forces that fall into them as well)
+    if (n > 0) {  // (the exact ghost rows, if any, receive the forces that fall into them as well: every rank
+                  // queues the same global list, include/sfl.h)
         HIP_TRY(sfl::launch_apply_forces(c->stream, c->vel, c->geom, clip_lo(c, c->g0 - c->v_ghost_valid),
                                          clip_hi(c, c->g1 + c->v_ghost_valid), c->d_force_cells, c->d_force_vel, n));
         ++c->vel_epoch;

@@ -287,7 +287,10 @@ SFL_API int sfl_subtract_gradient(sfl_context *ctx, float dx);
 SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega);
 /* Queue point forces applied by the next sfl_step between the velocity advection and the
  * divergence (ino:264-269): velocity[index(cells[2k], cells[2k+1])] = (vel[2k], vel[2k+1])
- * in SIMULATION coordinates (the sketch's x/y swap is the caller's business).               */
+ * in SIMULATION coordinates (the sketch's x/y swap is the caller's business), GLOBAL cell
+ * indices.  On slabs EVERY rank queues the SAME list: a rank applies the cells that fall into
+ * its rows and into the ghost row next to each cut, which sfl_step keeps exact instead of
+ * exchanging it again (a list that differs between ranks gives a wrong divergence at the cuts).   */
 SFL_API int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n);
 
 /* --- initial condition of the sketch (setup(), ino:196-241): velocity = 0; dye = three
