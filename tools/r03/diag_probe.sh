@@ -1,5 +1,6 @@
 #!/bin/bash
 # r03: which ingredient costs what when the waves of a SIMD share it fairly (PRIO_LEVELS = 4)?
+# (binaries: bash tools/r03/build_probes.sh diag)
 # d1 no lane shifts, d2 no rhs ring (LDS), d3 no global loads, d4 all three, d5 no boundary path; prio4 = everything
 set -u
 export TMPDIR=/tmp
