@@ -480,8 +480,12 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     sor::Tiling t1 = tiling(rows.g_begin, rows.g_end), t2 = tiling(rows.g2_begin, rows.g2_end);
     const int tiles = t1.n_tiles + t2.n_tiles;
     if (tiles == 0) return hipSuccess;
-    // rotating issue priority (WaveCommon::next_turn) only when every tile is resident from the start
-    t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE : tiles <= resident_waves<B, NS, DX1, ZERO_IN>();
+    // rotating issue priority (WaveCommon::next_turn) only when every tile is resident from the start AND the SIMDs
+    // hold three waves: with two, the second wave fills the first one's gaps anyway (8192 x 1024, NS = 10: 24.6 us per
+    // launch with and without), and a thin slab's launches run next to the halo exchange's kernels, which should
+    // not have to compete with raised priorities
+    t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE
+                                                : tiles <= resident_waves<B, NS, DX1, ZERO_IN>() && 2 * tiles > 5 * device_simds();
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm);
     return hipGetLastError();
