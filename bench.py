@@ -239,6 +239,9 @@ def parse_args(argv=None):
                          "ms per solve of that rank = the per-GPU critical path without the wire; results next to "
                          "the cuts are meaningless, so parity and the CPU baseline are skipped")
     ap.add_argument("--of", type=int, default=8, help="group size for --emulate-rank")
+    ap.add_argument("--wire-us", type=int, default=0,
+                    help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
+                         "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
@@ -374,6 +377,8 @@ def run_rank(args):
             sys.exit("--emulate-rank runs on ONE GPU")
         s = sfl.Solver(size, dim_y, device=local_rank, rank=args.emulate_rank, nranks=args.of)
         s.comm_emulate()
+        if args.wire_us:
+            s.set_option(capi.OPT_EMULATE_WIRE_US, args.wire_us)
         args.no_cpu_baseline = True
     else:
         s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
@@ -552,6 +557,7 @@ def run_rank(args):
             "cell_iters_per_sec_of_this_rank": cells * iters * args.steps / elapsed,
             "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
+            "emulated_wire_us": args.wire_us,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None, **({"sim_steps_note": sim_note} if sim_note else {}),
             "note": "one rank's program alone on one GPU, halo messages as self-copies of the same size on the "
                     "exchange stream (sfl_comm_emulate); values next to the cuts are meaningless",

@@ -6,8 +6,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# SFL_LIB: an alternative build of the same library (A/B experiments with compile-time variants)
-LIB_PATH = os.environ.get("SFL_LIB") or os.path.join(_PKG, "lib", "libsfl_hip.so")
+LIB_PATH = os.path.join(_PKG, "lib", "libsfl_hip.so")   # the one product library (A/B builds: tools/with_lib.py)
 
 OK, ERR_INVALID, ERR_HIP, ERR_RCCL, ERR_NOMEM, ERR_STATE, ERR_HALO = 0, -1, -2, -3, -4, -5, -6
 FIELD_VELOCITY, FIELD_COLOR, FIELD_DIVERGENCE, FIELD_PRESSURE = 0, 1, 2, 3
@@ -19,6 +18,7 @@ OPT_SOR_OVERLAP = 8
 OPT_ADVECT_KERNEL = 9
 OPT_FUSE_DIVERGENCE = 10
 OPT_SMALL_GRID = 11
+OPT_EMULATE_WIRE_US = 12
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
@@ -26,6 +26,11 @@ UNIQUE_ID_BYTES = 128
 class PlanStep(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("kind", "field", "rows", "g_begin", "g_end", "nsweeps",
                                          "first_colour", "from_zero")]
+
+
+class Drag(C.Structure):
+    """struct drag of the sketch (ino:45-48): graphics coordinates."""
+    _fields_ = [("coord_x", C.c_uint16), ("coord_y", C.c_uint16), ("vel_x", C.c_float), ("vel_y", C.c_float)]
 
 
 class SflError(RuntimeError):
@@ -107,6 +112,7 @@ SIGNATURES = {
     "sfl_subtract_gradient": (_i, [_ctx, _f]),
     "sfl_step": (_i, [_ctx, _f, _f, _i, _f]),
     "sfl_queue_forces": (_i, [_ctx, _pi, _pf, _i]),
+    "sfl_queue_drags": (_i, [_ctx, C.c_void_p, _i]),
     "sfl_setup_sketch_fields": (_i, [_ctx]),
     "sfl_render_rgb565": (_i, [_ctx, _i, _i, C.POINTER(C.c_uint16), _sz]),
     "sfl_synchronize": (_i, [_ctx]),

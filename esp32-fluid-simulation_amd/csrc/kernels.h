@@ -142,6 +142,9 @@ hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_
 hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
                                const int *cells_ij, const float *vel_xy, int n);
 
+// Measurement aid: one wave idling for `us` microseconds (the emulated wire of sfl_comm_emulate).
+hipError_t launch_spin_us(hipStream_t s, int us);
+
 // Initial condition of the sketch's setup() (ino:196-241): zero velocity, three dye sectors, two
 // in-place sequential 1-2-1 blurs; WHOLE-DOMAIN arrays.
 hipError_t launch_setup_sketch_fields(hipStream_t s, float *v, uint32_t *colour, int dim_x, int dim_y);

@@ -147,9 +147,10 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0;
 
     ncclComm_t comm = nullptr;
+    bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
     bool emulated = false;              // sfl_comm_emulate: one rank's program with self-copies as transport
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
@@ -307,6 +308,7 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         // so results next to the cuts mean nothing; launches, copies and their ordering are the rank's program.
         SFL_TRY(use_device(c));
         hipStream_t st = on ? on : c->stream;
+        HIP_TRY(sfl::launch_spin_us(st, c->opt_emulate_wire_us));   // the wire a self-copy does not have (0: none)
         if (c->rank > 0)
             HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - skip - rows), row_ptr(c, c->g0 + skip), bytes,
                                    hipMemcpyDeviceToDevice, st));
@@ -741,7 +743,17 @@ int default_device()
 // tools/ubench_host_register.hip), the solve takes 1.8 ms: 11.4 ms with the context retained
 // (profiles/r03_host_dropin.txt).
 constexpr int64_t kHostCacheCells = 1 << 26;
-thread_local sfl_context *g_host_cached = nullptr;
+// (released when the thread ends -- a raw thread_local pointer kept up to 3.25 GB of device memory per exited
+// thread, ADVICE r03 -- by sfl_host_release(), by a change of shape and by a failing call)
+struct HostCache {
+    sfl_context *ctx = nullptr;
+    ~HostCache()
+    {
+        if (ctx) (void)sfl_destroy(ctx);
+        ctx = nullptr;
+    }
+};
+thread_local HostCache g_host_cache;
 
 struct HostCtx {
     sfl_context *c = nullptr;
@@ -750,7 +762,7 @@ struct HostCtx {
     int acquire(int dim_x, int dim_y)
     {
         const int dev = default_device();
-        sfl_context *k = g_host_cached;
+        sfl_context *k = g_host_cache.ctx;
         if (k && k->device == dev && k->dim_x == dim_x && k->gdim_y == dim_y) {
             c = k;
             cached = true;
@@ -763,12 +775,12 @@ struct HostCtx {
             return SFL_OK;
         }
         if (k) {
-            g_host_cached = nullptr;
+            g_host_cache.ctx = nullptr;
             sfl_destroy(k);
         }
         SFL_TRY(sfl_create(&c, dev, dim_x, dim_y));
         if ((int64_t)dim_x * dim_y <= kHostCacheCells) {
-            g_host_cached = c;
+            g_host_cache.ctx = c;
             cached = true;
         }
         return SFL_OK;
@@ -782,7 +794,7 @@ struct HostCtx {
     {
         if (!c) return;
         if (cached && ok) return;
-        if (cached) g_host_cached = nullptr;  // unknown state after a failure: start afresh
+        if (cached) g_host_cache.ctx = nullptr;  // unknown state after a failure: start afresh
         sfl_destroy(c);
     }
 };
@@ -1020,6 +1032,10 @@ static int set_option_one(sfl_context *c, int option, int value)
             if (value < 0 || value > 2) return fail(SFL_ERR_INVALID, "advection kernel must be 0, 1 or 2");
             c->opt_advect_kernel = value;
             return SFL_OK;
+        case SFL_OPT_EMULATE_WIRE_US:
+            if (value < 0 || value > 10000) return fail(SFL_ERR_INVALID, "emulated wire delay must be 0..10000 us");
+            c->opt_emulate_wire_us = value;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -1041,7 +1057,12 @@ static int set_option_one(sfl_context *c, int option, int value)
 int sfl_set_option(sfl_context *ctx, int option, int value)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
-    for (sfl_context *c : peers_of(ctx)) SFL_TRY(set_option_one(c, option, value));
+    for (sfl_context *c : peers_of(ctx)) {
+        SFL_TRY(set_option_one(c, option, value));
+        // RCCL ranks: the option block is compared again, collectively, by the next operator (every rank that
+        // changed an option does so at the same point of its program; sfl_comm_check_options does it at once)
+        if (c->comm) c->options_dirty = true;
+    }
     return SFL_OK;
 }
 
@@ -1061,6 +1082,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_ADVECT_KERNEL: *value = c->opt_advect_kernel; return SFL_OK;
         case SFL_OPT_FUSE_DIVERGENCE: *value = c->opt_fuse_divergence; return SFL_OK;
         case SFL_OPT_SMALL_GRID: *value = c->opt_small_grid; return SFL_OK;
+        case SFL_OPT_EMULATE_WIRE_US: *value = c->opt_emulate_wire_us; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -1135,6 +1157,7 @@ int sfl_comm_check_options(sfl_context *c)
                 }
     } while (false);
     (void)hipFree(dev);
+    if (rc == SFL_OK) c->options_dirty = false;
     return rc;
 }
 
@@ -1147,8 +1170,17 @@ int sfl_comm_attach(sfl_context *c, const void *id, size_t id_bytes)
     memcpy(&uid, id, sizeof uid);
     NCCL_TRY(ncclCommInitRank(&c->comm, c->nranks, uid, c->rank));
     // the ranks are separate processes: a rank created for another domain or with other options would run a
-    // different program (mismatched sends / receives: a hang or silently wrong halos) -- refuse it here
-    return sfl_comm_check_options(c);
+    // different program (mismatched sends / receives: a hang or silently wrong halos) -- refuse it here, and
+    // do not stay attached to a group this rank does not fit
+    const int rc = sfl_comm_check_options(c);
+    if (rc != SFL_OK) {
+        const std::string why = g_error;
+        if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+        g_error = why;
+    }
+    return rc;
 }
 
 int sfl_comm_emulate(sfl_context *c)
@@ -1260,6 +1292,16 @@ int sfl_field_device_ptr(sfl_context *c, int field, void **dev_ptr)
     const size_t eb = field_elem_bytes(field);
     if (!eb) return fail(SFL_ERR_INVALID, "unknown field id %d", field);
     SFL_TRY(ensure_field(c, field));
+    // The pointer is writable: whatever was known about the field's ghost rows, or about the reach of the
+    // velocity's back-traces, may be stale once the caller has used it (a velocity written through
+    // the pointer was advected on the previous field's halo).  Treated like an upload.
+    for (sfl_context *m : peers_of(c)) {
+        if (field == SFL_FIELD_VELOCITY) {
+            ++m->vel_epoch;
+            m->v_ghost_valid = 0;
+        }
+        if (field == SFL_FIELD_PRESSURE) m->p_ghost_valid = 0;
+    }
     *dev_ptr = static_cast<char *>(field_ptr(c, field)) + c->owned_offset_cells() * eb;
     return SFL_OK;
 }
@@ -1565,6 +1607,27 @@ int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy,
     return SFL_OK;
 }
 
+// The sketch's own message (ino:45-48) with the sketch's own transform (ino:264-269): the touch task speaks
+// graphics coordinates, the sim Cartesian ones rotated by 90 degrees -- cell = index(coords.y, coords.x),
+// velocity = (velocity.y, velocity.x).
+int sfl_queue_drags(sfl_context *ctx, const sfl_drag *msgs, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !msgs)) return fail(SFL_ERR_INVALID, "bad arguments");
+    std::vector<int> cells((size_t)2 * n);
+    std::vector<float> vel((size_t)2 * n);
+    for (int k = 0; k < n; ++k) {
+        const int i = msgs[k].coord_y, j = msgs[k].coord_x;   // ino:265: index(msg.coords.y, msg.coords.x, N_ROWS)
+        if (i >= ctx->dim_x || j >= ctx->gdim_y)
+            return fail(SFL_ERR_INVALID, "drag %d: coords (x %d, y %d) address cell (i %d, j %d) outside the %d x %d "
+                        "domain (the sketch would write out of bounds)", k, j, i, i, j, ctx->dim_x, ctx->gdim_y);
+        cells[2 * k] = i;
+        cells[2 * k + 1] = j;
+        vel[2 * k] = msgs[k].vel_y;                           // ino:266: swapped(msg.velocity.y, msg.velocity.x)
+        vel[2 * k + 1] = msgs[k].vel_x;
+    }
+    return sfl_queue_forces(ctx, cells.data(), vel.data(), n);
+}
+
 // Copies the queued (cell, velocity) pairs to the device (asynchronously, through pinned staging) and empties the
 // queue; *count = how many now wait in d_force_cells / d_force_vel for the kernel that applies them.
 static int stage_queued_forces(sfl_context *c, int *count)
@@ -1788,6 +1851,7 @@ static int post_reach_report(sfl_context *ctx, const std::vector<sfl_context *> 
 // was short.  Cheap when nothing is pending.  Every entry point that reads or writes the fields calls it.
 static int settle_color(sfl_context *ctx)
 {
+    if (ctx->comm && ctx->options_dirty) SFL_TRY(sfl_comm_check_options(ctx));   // (collective; see sfl_set_option)
     if (!ctx->color_unsettled) return SFL_OK;
     std::vector<sfl_context *> peers = peers_of(ctx);
     int reach = 0, reach_ext = 0, flag = 0;
@@ -1856,7 +1920,7 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     // its neighbours' rows in place; and the solve leaves one ghost row of p exact (plan tail), which is all
     // subtract_gradient reads beyond the cut.
     AdvectPlan pv;
-    pv.flag = false;
+    pv.flag = true;   // exact by construction; armed all the same (a back-trace that leaves it -> SFL_ERR_HALO at sfl_synchronize)
     int extend = 0;
     if (reach_v_ext <= limit) {
         pv.halo = std::max(reach_v_ext, 1);
@@ -2079,8 +2143,8 @@ int sfl_host_poisson_solve(float *p, const float *div, int dim_x, int dim_y, flo
 
 int sfl_host_release(void)
 {
-    sfl_context *k = g_host_cached;
-    g_host_cached = nullptr;
+    sfl_context *k = g_host_cache.ctx;
+    g_host_cache.ctx = nullptr;
     return k ? sfl_destroy(k) : SFL_OK;
 }
 

@@ -79,14 +79,23 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
         // extra[j] = ghost rows that must still be valid after launch j = passes of the launches up to and
         // including the next exchange launch (whose owned rows are produced from what is there)
         std::vector<int> xchg_before(n, 0), extra(n, 0);
-        int budget = halo - tail;
-        for (size_t j = 0; j < n; ++j) {
-            if (passes[j] > budget) {  // launch j does not fit what is left: the exchange goes before launch j - 1
-                xchg_before[j - 1] = 1;
-                budget = halo - tail - passes[j - 1];
+        auto place_exchanges = [&](int t, std::vector<int> *where) {
+            int count = 0, budget = halo - t;
+            for (size_t j = 0; j < n; ++j) {
+                if (passes[j] > budget) {  // launch j does not fit what is left: the exchange goes before launch j - 1
+                    if (where) (*where)[j - 1] = 1;
+                    ++count;
+                    budget = halo - t - passes[j - 1];
+                }
+                budget -= passes[j];
             }
-            budget -= passes[j];
-        }
+            return count;
+        };
+        // The tail saves ONE 1-row exchange after the solve; it must not cost exchanges inside it (fuse 16 / halo 64
+        // is one row short of four launches per superstep with a tail: 11 exchanges instead of 7 over 200
+        // iterations).  Dropped then -- subtract_gradient exchanges its row as it always could.
+        if (tail > 0 && place_exchanges(tail, nullptr) > place_exchanges(0, nullptr)) tail = 0;
+        place_exchanges(tail, &xchg_before);
         extra[n - 1] = tail;
         for (size_t j = n; j-- > 0;) {
             // rows needed after launch j: the following launches up to and including the next exchange launch

@@ -73,6 +73,12 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #ifndef SFL_PROBE_NO_LOAD
 #define SFL_PROBE_NO_LOAD 0  // diagnostic builds only: no global loads (wrong results)
 #endif
+#ifndef SFL_PROBE_P_LOAD_AUX
+#define SFL_PROBE_P_LOAD_AUX 0   // diagnostic builds only: cache-policy bits of the p loads (16 = sc1: agent scope, bypasses L1)
+#endif
+#ifndef SFL_PROBE_P_STORE_AUX
+#define SFL_PROBE_P_STORE_AUX 0  // diagnostic builds only: ... of the p stores (16 = sc1: written through the XCD's L2)
+#endif
 #ifndef SFL_PROBE_SHIFT
 #define SFL_PROBE_SHIFT 0  // diagnostic builds only (tools/sor_clock_probe.hip): 1 = no lane shift at all, 2 = row_shr / row_shl
 #endif
@@ -250,7 +256,7 @@ struct Lane2 : WaveCommon {
         }
         if (!ZERO_IN) {
             if (VEC) {
-                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, 0));
+                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, SFL_PROBE_P_LOAD_AUX));
                 pa = q.x;
                 pb = q.y;
             } else {
@@ -268,7 +274,7 @@ struct Lane2 : WaveCommon {
                 v2f o;
                 o.x = a;
                 o.y = b;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, SFL_PROBE_P_STORE_AUX ? SFL_PROBE_P_STORE_AUX : NT ? 2 : 0);
             }
         } else {
             if (a_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a), rs_out, off_out, soff, 0);
@@ -297,13 +303,15 @@ struct Lane2 : WaveCommon {
 
 // Occupancy the register allocator must keep: a launch lasts as long as one wave's chain of iterations, and
 // that chain is served best with >= 3 waves on the SIMD (NS >= 12: 168 VGPRs) / 4 (NS <= 10: 128).
+// NS = 14 does not fit 168 registers on its boundary path (2 - 7 registers spilled to scratch in round 3's builds);
+// it is never the automatic choice, so it is simply given the registers it asks for (2 waves per SIMD).
 #ifndef SFL_MIN_WAVES_DEEP
 #define SFL_MIN_WAVES_DEEP 3
 #endif
 #ifndef SFL_PROBE_NO_EDGE
 #define SFL_PROBE_NO_EDGE 0  // diagnostic builds only: every tile takes the interior path (wrong results at the walls)
 #endif
-constexpr int min_waves_per_simd(int ns) { return ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }
+constexpr int min_waves_per_simd(int ns) { return ns == 14 ? 2 : ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))

@@ -445,6 +445,22 @@ hipError_t launch_render_rgb565(hipStream_t s, uint16_t *image, const uint32_t *
     return hipGetLastError();
 }
 
+// One wave that does nothing for `us` microseconds of the constant 100 MHz real-time clock: the wire delay of an
+// EMULATED halo message (sfl_comm_emulate + SFL_OPT_EMULATE_WIRE_US; measurement aid, never on a product path).
+__global__ void spin_us_kernel(int us)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ticks = (unsigned long long)us * 100ull;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+hipError_t launch_spin_us(hipStream_t s, int us)
+{
+    if (us <= 0) return hipSuccess;
+    spin_us_kernel<<<1, 64, 0, s>>>(us);
+    return hipGetLastError();
+}
+
 hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
                                const int *cells_ij, const float *vel_xy, int n)
 {

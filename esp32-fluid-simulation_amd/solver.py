@@ -183,6 +183,13 @@ class Solver:
             self._h, cells.ctypes.data_as(C.POINTER(C.c_int)),
             vel.ctypes.data_as(C.POINTER(C.c_float)), len(cells)))
 
+    def queue_drags(self, drags):
+        """drags: iterable of (coords_x, coords_y, velocity_x, velocity_y) in the sketch's graphics coordinates
+        (struct drag, ino:45-48); transformed like ino:264-269 by the library."""
+        drags = list(drags)
+        arr = (capi.Drag * max(len(drags), 1))(*[capi.Drag(int(a), int(b), float(c), float(d)) for a, b, c, d in drags])
+        capi.check(self._lib.sfl_queue_drags(self._h, C.cast(arr, C.c_void_p), len(drags)))
+
     def setup_sketch_fields(self):
         """Velocity = 0, dye = the sketch's blurred three-sector pattern (setup(), ino:196-241)."""
         capi.check(self._lib.sfl_setup_sketch_fields(self._h))

@@ -106,6 +106,10 @@ extern "C" {
                                      sfl_step run as ONE launch of one workgroup with the fields in
                                      LDS (the sketch's 61 x 81 grid: one launch instead of six to
                                      ten); 0 = the general kernels                                 */
+#define SFL_OPT_EMULATE_WIRE_US 12 /* sfl_comm_emulate only (measurement aid): every emulated halo message is held
+                                     back by this many microseconds on the exchange stream before its copy
+                                     starts -- the latency of a real xGMI send / receive that a self-copy does
+                                     not have; 0 (default) .. 10000                                   */
 
 typedef struct sfl_context sfl_context;
 
@@ -262,7 +266,9 @@ SFL_API int sfl_group_link(sfl_context **ctxs, int n);
 SFL_API int sfl_upload(sfl_context *ctx, int field, const void *host, size_t bytes);
 SFL_API int sfl_download(sfl_context *ctx, int field, void *host, size_t bytes);
 /* Device pointer of the first OWNED row of the field's CURRENT buffer (zero-copy interop; the
- * context keeps ownership).  Velocity, colour and pressure are ping-ponged between two buffers by
+ * context keeps ownership).  The pointer is writable, so the query counts as a write from outside (as
+ * sfl_upload does): on slabs the next operator exchanges / measures again instead of trusting ghost rows
+ * and back-trace reaches it knew before.  Velocity, colour and pressure are ping-ponged between two buffers by
  * the operators that rewrite them (advect: ino:255,286; the fused SOR launches), so the pointer
  * is valid only until the next operator that writes that field -- sfl_step writes all of them:
  * query again after every such call (the query costs nothing).  Asynchronous work may still be
@@ -292,6 +298,16 @@ SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omeg
  * its rows and into the ghost row next to each cut, which sfl_step keeps exact instead of
  * exchanging it again (a list that differs between ranks gives a wrong divergence at the cuts).   */
 SFL_API int sfl_queue_forces(sfl_context *ctx, const int *cells_ij, const float *vel_xy, int n);
+/* The same in the sketch's own terms: `struct drag` as the touch task queues it (ino:45-48: Vector2<uint16_t>
+ * coords, Vector2<float> velocity, GRAPHICS coordinates) with the transform loop() applies to it (ino:264-269):
+ * cell = index(coords.y, coords.x), velocity = (velocity.y, velocity.x).  sizeof(sfl_drag) == sizeof(struct drag)
+ * == 12, same member order: a drag_queue message can be passed as it is.  Coordinates outside the domain are
+ * refused (SFL_ERR_INVALID, nothing queued); the sketch would write out of bounds.                        */
+typedef struct sfl_drag {
+    uint16_t coord_x, coord_y; /* msg.coords.x, msg.coords.y     */
+    float vel_x, vel_y;        /* msg.velocity.x, msg.velocity.y */
+} sfl_drag;
+SFL_API int sfl_queue_drags(sfl_context *ctx, const sfl_drag *msgs, int n);
 
 /* --- initial condition of the sketch (setup(), ino:196-241): velocity = 0; dye = three
  *     120-degree sectors around the centre chosen by atan2f, then the sketch's two in-place

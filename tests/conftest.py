@@ -23,14 +23,14 @@ def pytest_configure(config):
 
 def _ensure_built():
     """Build whatever is missing (fresh clone): the product library (hipcc cross-compiles gfx950
-    without a GPU), the C++ host layer, the oracle and the wave emulator.  No-ops when present."""
+    without a GPU), the C++ host layer and the oracle.  No-ops when present.  (The CPU wave emulator is built by
+    the fixture of tests/test_sor_stream_emulation.py: it does not travel to the GPU box, .gpurunignore.)"""
     import subprocess
     pkg = os.path.join(ROOT, "esp32-fluid-simulation_amd")
     jobs = [
         (os.path.join(pkg, "lib", "libsfl_hip.so"), ["make", "-C", os.path.join(pkg, "csrc"), "-j6"]),
         (os.path.join(pkg, "lib", "libsfl_dropin.so"), ["make", "-C", os.path.join(pkg, "host")]),
         (os.path.join(ROOT, "oracle", "libsf_oracle.so"), ["make", "-C", os.path.join(ROOT, "oracle")]),
-        (os.path.join(ROOT, "tests", "cpp", "libsor_stream_emu.so"), ["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-j4"]),
     ]
     for artefact, cmd in jobs:
         if not os.path.exists(artefact):

@@ -1087,3 +1087,143 @@ def test_emulated_rank_runs_its_program_alone(sfl):
         for _ in range(3):
             s.step(DT, 1.0, iters, OMEGA)
         s.synchronize()
+
+
+# ---- round 4: the BASELINE multi-GPU configurations in full on eight virtual ranks -----------------------------
+def oracle_step(oracle, v, c, iters, forces=None):
+    """One sim step of the checker in the order of ino:252-287, drag forces (cells (i, j), velocities) written
+    between the velocity advection and the divergence (ino:264-269).  Returns (v, div, p, colour)."""
+    va = oracle.advect_vec2f(v, v, DT, True)
+    if forces:
+        for (i, j), u in zip(*forces):
+            va[j, i] = u
+    d = oracle.divergence(va, 1.0)
+    p = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    vp = oracle.subtract_gradient(va, p, 1.0)
+    return vp, d, p, oracle.advect_vec3uq32(c, vp, DT, False)
+
+
+def test_baseline_config5_in_full_on_eight_virtual_ranks(sfl, oracle):
+    """BASELINE config 5 at FULL size -- 16384 x 16384, 200 SOR iterations, eight 2048-row slabs, every option on
+    auto (fuse 16, 64-row halo: 25 launches, the rhs exchange and seven early p exchanges with their ghost-row
+    launches) -- executed by eight virtual ranks on one GPU, every cell against the oracle (poisson.cpp:114-125;
+    ~45 s of one host core)."""
+    dim, iters, nranks = 16384, 200, 8
+    rng = np.random.default_rng(1605)
+    d = (rng.standard_normal((dim, dim), dtype=np.float32) * np.float32(0.1))
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim, dim, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[5].last_solve_info()
+        for s in slabs:     # slab by slab: no second 1 GiB copy of the field on the host
+            assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), want[s.row_begin:s.row_end],
+                             f"C5 in full: slab {s.rank} of 8")
+    finally:
+        for s in slabs:
+            s.close()
+    assert info["fuse"] == 16 and info["launches"] == 25
+    assert info["exchanges"] == plan_exchanges(sfl, dim, nranks, iters, 16)
+
+
+def test_baseline_config4_whole_sim_step_on_eight_virtual_ranks(sfl, oracle):
+    """BASELINE config 4's WHOLE sim step (ino:252-287) at full size: 8192 x 8192, 80 SOR iterations, eight 1024-row
+    slabs on eight virtual ranks, everything on auto (automatic advection halo: measured for the first step, known
+    for the second; dye halo sent early; solve with a one-row tail), two steps, with drag forces thrown onto and
+    next to two cuts before the second one (ino:264-269).  Every cell of every field against the oracle."""
+    dim, iters, nranks = 8192, 80, 8
+    rng = np.random.default_rng(84)
+    v = (rng.uniform(-1, 1, (dim, dim, 2)) * 100).astype(np.float32)
+    c = rng.integers(0, 2 ** 31, (dim, dim, 3), dtype=np.uint32)
+    # drags in the sketch's graphics coordinates: (coords.x = j, coords.y = i, velocity.x -> v.y, velocity.y -> v.x)
+    drags = [(1023, 77, 250.0, -40.0), (1024, 78, -300.0, 55.0), (1025, 4000, 90.0, 90.0), (6143, 8191, -120.0, 10.0),
+             (6144, 0, 400.0, -400.0), (5000, 5000, 33.0, -66.0)]
+    slabs = [sfl.Solver(dim, dim, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        vo, co = v, c
+        for step in range(2):
+            forces = None
+            if step == 1:
+                slabs[0].queue_drags(drags)     # (a linked group shares one queue; RCCL ranks each queue the same list)
+                forces = ([(y, x) for x, y, _, _ in drags], [(vy, vx) for _, _, vx, vy in drags])
+            slabs[0].step(DT, 1.0, iters, OMEGA)
+            vo, do, po, co = oracle_step(oracle, vo, co, iters, forces)
+        slabs[0].synchronize()
+        for s in slabs:
+            rows = slice(s.row_begin, s.row_end)
+            assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), vo[rows], f"velocity, slab {s.rank}")
+            assert_bit_equal(s.download(sfl.capi.FIELD_DIVERGENCE), do[rows], f"divergence, slab {s.rank}")
+            assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), po[rows], f"pressure, slab {s.rank}")
+            assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), co[rows], f"colour, slab {s.rank}")
+    finally:
+        for s in slabs:
+            s.close()
+
+
+def test_drag_messages_take_the_sketchs_transform(sfl, oracle):
+    """sfl_queue_drags: the sketch's struct drag (ino:45-48) with the x / y swap of ino:264-269 done by the library --
+    identical to sfl_queue_forces with the swap done by hand, and to the oracle; out-of-domain coordinates refused."""
+    dim_x, dim_y, iters = 61, 81, 6
+    v, c, _ = random_fields(dim_x, dim_y, 45, 40.0)
+    drags = [(10, 3, 5.5, -7.25), (80, 60, -100.0, 3.0), (0, 0, 1.0, 2.0), (10, 3, 9.0, 9.5)]   # (coords.x, coords.y, vel.x, vel.y)
+    cells = [(y, x) for x, y, _, _ in drags]
+    vels = [(vy, vx) for _, _, vx, vy in drags]
+    want = oracle_step(oracle, v, c, iters, (cells, vels))
+    for small in (1, 0):
+        with sfl.Solver(dim_x, dim_y) as s:
+            s.set_option(sfl.capi.OPT_SMALL_GRID, small)
+            s.upload(sfl.capi.FIELD_VELOCITY, v)
+            s.upload(sfl.capi.FIELD_COLOR, c)
+            s.queue_drags(drags)
+            s.step(DT, 1.0, iters, OMEGA)
+            s.synchronize()
+            assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), want[0], f"velocity (small grid {small})")
+            assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), want[3], f"colour (small grid {small})")
+            with pytest.raises(sfl.SflError) as e:
+                s.queue_drags([(dim_y, 0, 1.0, 1.0)])       # coords.x addresses j: one past the last row
+            assert e.value.code == sfl.capi.ERR_INVALID
+            with pytest.raises(sfl.SflError):
+                s.queue_drags([(0, dim_x, 1.0, 1.0)])
+
+
+def test_device_pointer_counts_as_a_write_from_outside(sfl, oracle):
+    """sfl_field_device_ptr hands out a WRITABLE pointer.  A velocity written through it must not be
+    advected on the halo / reach the library knew for the previous field: four virtual ranks step once (the reach of
+    the slow field becomes 'known'), then a jet crossing the cuts is written through the pointers, and the next step
+    must still match the oracle."""
+    import ctypes as C
+    hipr = C.CDLL("libamdhip64.so")
+    hipr.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dim_x, dim_y, iters, nranks = 96, 256, 5, 4
+    v, c, _ = random_fields(dim_x, dim_y, 46, 20.0)
+    jet = v.copy()
+    jet[..., 1] = 30.0 * 11.5          # 11.5 rows per step: far beyond the reach of the first field (< 1 row)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        slabs[0].step(DT, 1.0, iters, OMEGA)
+        vo, do, po, co = oracle.step(v, c, DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        for s in slabs:
+            part = np.ascontiguousarray(jet[s.row_begin:s.row_end])
+            assert hipr.hipMemcpy(s.device_ptr(sfl.capi.FIELD_VELOCITY), part.ctypes.data, part.nbytes, 1) == 0   # H2D
+        slabs[0].step(DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()         # no SFL_ERR_HALO either
+        want = oracle.step(jet, co, DT, 1.0, iters, OMEGA)
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), want[0], "velocity after the write through the pointer")
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), want[3], "colour after the write through the pointer")
+    finally:
+        for s in slabs:
+            s.close()
