@@ -19,6 +19,7 @@ OPT_ADVECT_KERNEL = 9
 OPT_FUSE_DIVERGENCE = 10
 OPT_SMALL_GRID = 11
 OPT_EMULATE_WIRE_US = 12
+CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
@@ -86,6 +87,7 @@ SIGNATURES = {
     "sfl_sor_pass_plan": (_i, [_i, _i, _pi, _pi, _i]),
     "sfl_host_advect_vec2f": (_i, [_pf, _pf, _pf, _i, _i, _f, _i]),
     "sfl_host_advect_vec3uq32": (_i, [_pu, _pu, _pf, _i, _i, _f, _i]),
+    "sfl_host_advect_channels": (_i, [C.c_void_p, C.c_void_p, _pf, _i, _i, _f, _i, _i, _i]),
     "sfl_host_calculate_divergence": (_i, [_pf, _pf, _i, _i, _f]),
     "sfl_host_subtract_gradient": (_i, [_pf, _pf, _i, _i, _f]),
     "sfl_host_poisson_solve": (_i, [_pf, _pf, _i, _i, _f, _i, _f]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "sfl_field_device_ptr": (_i, [_ctx, _i, C.POINTER(C.c_void_p)]),
     "sfl_advect_velocity": (_i, [_ctx, _f, _i]),
     "sfl_advect_color": (_i, [_ctx, _f, _i]),
+    "sfl_advect_external": (_i, [_ctx, C.c_void_p, C.c_void_p, _i, _i, _f, _i]),
     "sfl_calculate_divergence": (_i, [_ctx, _f]),
     "sfl_poisson_solve": (_i, [_ctx, _f, _i, _f]),
     "sfl_subtract_gradient": (_i, [_ctx, _f]),

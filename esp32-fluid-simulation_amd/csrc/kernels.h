@@ -65,6 +65,11 @@ hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const u
 hipError_t launch_advect_divergence_tiled(hipStream_t s, float *next_v, float *div, const float *v, Slab g,
                                           float dt, bool no_slip, float two_dx_inv);
 
+// advect<T, float> of a WHOLE-DOMAIN field whose element is `channels` (1..3) consecutive 32-bit channels of one
+// kind (0 = float, 1 = UQ32 raw): every element type the reference's headers can express (advect_generic.hip).
+hipError_t launch_advect_channels(hipStream_t s, void *next_p, const void *p, const float *vel, int dim_x, int dim_y,
+                                  float dt, bool no_slip, int channels, int kind);
+
 // ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
 // `kernel` as for the advections: 1 = one thread per cell (stencil_kernels.hip), 2 = the 66 x 34 window of a
 // 64 x 32-cell tile staged in LDS (advect_tiled.hip), 0 = automatic (2 from kAdvectTiledMinCells cells).

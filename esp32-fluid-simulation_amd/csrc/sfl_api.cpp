@@ -1550,6 +1550,25 @@ static int advect_color_planned(sfl_context *ctx, const std::vector<sfl_context 
     return SFL_OK;
 }
 
+static int check_channels(int channels, int kind);
+
+int sfl_advect_external(sfl_context *c, void *next_p_dev, const void *p_dev, int channels, int kind, float dt,
+                        int no_slip)
+{
+    if (!c || !next_p_dev || !p_dev) return fail(SFL_ERR_INVALID, "NULL argument");
+    if (next_p_dev == p_dev) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
+    SFL_TRY(check_channels(channels, kind));
+    if (c->nranks != 1)
+        return fail(SFL_ERR_STATE, "sfl_advect_external needs a whole-domain context (slab %d/%d): the caller's array "
+                    "has no ghost rows", c->rank, c->nranks);
+    SFL_TRY(settle_color(c));
+    SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+    SFL_TRY(use_device(c));
+    HIP_TRY(sfl::launch_advect_channels(c->stream, next_p_dev, p_dev, c->vel, c->dim_x, c->gdim_y, dt, no_slip != 0,
+                                        channels, kind));
+    return SFL_OK;
+}
+
 int sfl_calculate_divergence(sfl_context *ctx, float dx)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
@@ -1920,7 +1939,9 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     // its neighbours' rows in place; and the solve leaves one ghost row of p exact (plan tail), which is all
     // subtract_gradient reads beyond the cut.
     AdvectPlan pv;
-    pv.flag = true;   // exact by construction; armed all the same (a back-trace that leaves it -> SFL_ERR_HALO at sfl_synchronize)
+    // exact by construction; armed all the same (a back-trace that leaves it -> SFL_ERR_HALO at sfl_synchronize) --
+    // except on an emulated rank, whose ghost rows hold copies of its own rows: meaningless values, timing only
+    pv.flag = !ctx->emulated;
     int extend = 0;
     if (reach_v_ext <= limit) {
         pv.halo = std::max(reach_v_ext, 1);
@@ -2103,6 +2124,36 @@ int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *v
     SFL_TRY(sfl_upload(t.c, SFL_FIELD_COLOR, p, (size_t)dim_x * dim_y * 12));
     SFL_TRY(sfl_advect_color(t.c, dt, no_slip));
     return t.done(sfl_download(t.c, SFL_FIELD_COLOR, next_p, (size_t)dim_x * dim_y * 12));
+}
+
+static int check_channels(int channels, int kind)
+{
+    if (channels < 1 || channels > 3 || (kind != SFL_CHANNEL_F32 && kind != SFL_CHANNEL_UQ32))
+        return fail(SFL_ERR_INVALID, "advect: element must be 1..3 channels of kind SFL_CHANNEL_F32 / SFL_CHANNEL_UQ32 "
+                    "(got %d x kind %d)", channels, kind);
+    return SFL_OK;
+}
+
+int sfl_host_advect_channels(void *next_p, const void *p, const float *vel, int dim_x, int dim_y, float dt,
+                             int no_slip, int channels, int kind)
+{
+    if (!next_p || !p || !vel) return fail(SFL_ERR_INVALID, "NULL field pointer");
+    if (next_p == p) return fail(SFL_ERR_INVALID, "advect: next_p must not alias p (advect.h:82)");
+    SFL_TRY(check_channels(channels, kind));
+    HostCtx t;
+    SFL_TRY(t.acquire(dim_x, dim_y));
+    sfl_context *c = t.c;
+    // the 12-byte dye buffers double as staging for any element of up to three channels
+    SFL_TRY(ensure(c, c->vel, 8, false));
+    SFL_TRY(ensure(c, c->col, 12, false));
+    SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    SFL_TRY(upload_raw(c, c->vel, vel, 8));
+    SFL_TRY(upload_raw(c, c->col, p, (size_t)channels * 4));
+    const hipError_t e = sfl::launch_advect_channels(c->stream, c->col_tmp, c->col, c->vel, dim_x, dim_y, dt,
+                                                     no_slip != 0, channels, kind);
+    const int rc = e == hipSuccess ? download_raw(c, c->col_tmp, next_p, (size_t)channels * 4)
+                                   : fail(SFL_ERR_HIP, "advect launch failed: %s", hipGetErrorString(e));
+    return t.done(rc);
 }
 
 int sfl_host_calculate_divergence(float *div, const float *v, int dim_x, int dim_y, float dx)

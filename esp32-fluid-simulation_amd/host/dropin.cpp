@@ -51,4 +51,12 @@ void advect_vec3uq32(Vector3<UQ32> *next_p, Vector3<UQ32> *p, Vector2<float> *ve
                                   no_slip),
          "advect<Vector3<UQ32>>");
 }
+
+void advect_channels(void *next_p, void *p, Vector2<float> *vel, int dim_x, int dim_y, float dt, bool no_slip,
+                     int channels, bool uq32)
+{
+    must(sfl_host_advect_channels(next_p, p, flat(vel), dim_x, dim_y, dt, no_slip, channels,
+                                  uq32 ? SFL_CHANNEL_UQ32 : SFL_CHANNEL_F32),
+         "advect<T>");
+}
 }  // namespace sfl_dropin

@@ -164,6 +164,10 @@ class Solver:
     def advect_color(self, dt, no_slip=False):
         capi.check(self._lib.sfl_advect_color(self._h, dt, int(no_slip)))
 
+    def advect_external(self, next_p_dev: int, p_dev: int, channels: int, kind: int, dt, no_slip):
+        """A field of the caller's (device pointers) advected with the resident velocity (sfl_advect_external)."""
+        capi.check(self._lib.sfl_advect_external(self._h, next_p_dev, p_dev, channels, kind, dt, int(no_slip)))
+
     def calculate_divergence(self, dx=1.0):
         capi.check(self._lib.sfl_calculate_divergence(self._h, dx))
 
@@ -273,6 +277,20 @@ class HostPath:
         out = np.empty_like(p)
         capi.check(self._lib.sfl_host_advect_vec3uq32(_up(out), _up(p), _fp(vel), dim_x, dim_y, dt,
                                                       int(no_slip)))
+        return out
+
+    def advect_channels(self, p, vel, dt, no_slip):
+        """advect<T, float> for T = float / UQ32 / Vector2 / Vector3 of either (sfl_host_advect_channels): `p` is
+        float32 or uint32 (UQ32 raw), shape [dim_y, dim_x] or [dim_y, dim_x, 2 | 3]."""
+        dim_x, dim_y = self._dims(vel)
+        if p.dtype not in (np.float32, np.uint32):
+            raise TypeError("element channels are float32 or uint32 (UQ32 raw)")
+        p, vel = np.ascontiguousarray(p), np.ascontiguousarray(vel, np.float32)
+        channels = 1 if p.ndim == 2 else int(p.shape[2])
+        out = np.empty_like(p)
+        capi.check(self._lib.sfl_host_advect_channels(out.ctypes.data, p.ctypes.data, _fp(vel), dim_x, dim_y, dt,
+                                                      int(no_slip), channels,
+                                                      capi.CHANNEL_UQ32 if p.dtype == np.uint32 else capi.CHANNEL_F32))
         return out
 
     def divergence(self, v, dx=1.0):

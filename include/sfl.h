@@ -198,6 +198,15 @@ SFL_API int sfl_host_advect_vec2f(float *next_p, const float *p, const float *ve
 /* advect<Vector3<UQ32>, float>    advect.h:74-85 with uq32.h:13,15 (ino:282)               */
 SFL_API int sfl_host_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const float *vel,
                                      int dim_x, int dim_y, float dt, int no_slip);
+/* advect<T, float>                advect.h:74-85 for EVERY element type the reference's headers can express:
+ * T = `channels` (1..3) consecutive 32-bit channels of one `kind` -- float, Vector2<float>, Vector3<float>
+ * (SFL_CHANNEL_F32) or UQ32, Vector2<UQ32>, Vector3<UQ32> (SFL_CHANNEL_UQ32; vector.h:4-126, uq32.h:8-16).
+ * sample() (advect.h:24-72) acts channel by channel on all of them; the sketch's two instantiations
+ * (2 x f32, 3 x uq32) take the same kernels as the two entry points above.                     */
+#define SFL_CHANNEL_F32 0
+#define SFL_CHANNEL_UQ32 1
+SFL_API int sfl_host_advect_channels(void *next_p, const void *p, const float *vel, int dim_x, int dim_y,
+                                     float dt, int no_slip, int channels, int kind);
 /* calculate_divergence            finitediff.h:6-7, finitediff.cpp:9-39                     */
 SFL_API int sfl_host_calculate_divergence(float *div, const float *v, int dim_x, int dim_y,
                                           float dx);
@@ -288,6 +297,12 @@ SFL_API int sfl_calculate_divergence(sfl_context *ctx, float dx);
 SFL_API int sfl_poisson_solve(sfl_context *ctx, float dx, int iters, float omega);
 /* velocity <- subtract_gradient(velocity, pressure, dx)     ino:276     */
 SFL_API int sfl_subtract_gradient(sfl_context *ctx, float dx);
+/* next_p <- advect(p, velocity, dt, no_slip) for a field of the CALLER's, resident on the context's device
+ * (advect.h:74-85; element = `channels` x `kind` as for sfl_host_advect_channels): further quantities carried by
+ * the flow -- a temperature, a second dye -- without a round trip through the host.  Whole-domain contexts only;
+ * next_p_dev must not alias p_dev; asynchronous on the context's stream (sfl_synchronize before reading).   */
+SFL_API int sfl_advect_external(sfl_context *ctx, void *next_p_dev, const void *p_dev, int channels, int kind,
+                                float dt, int no_slip);
 /* One sim step in the order of ino:252-287: advect velocity (no-slip), [apply queued
  * forces], divergence, poisson_solve, subtract_gradient, advect colour (free-slip).         */
 SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega);

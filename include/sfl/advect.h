@@ -4,10 +4,15 @@
 //     template <class T, class U>
 //     void advect(T *next_p, T *p, Vector2<U> *vel, int dim_x, int dim_y, float dt, bool no_slip);
 //
-// The two instantiations the sketch uses are GPU paths (ino:253 and ino:282):
-//     T = Vector2<float>, U = float   ->  sfl_host_advect_vec2f
-//     T = Vector3<UQ32>,  U = float   ->  sfl_host_advect_vec3uq32
-// Any other element type is rejected at compile time: there is no CPU fallback in this library.
+// advect() over a whole field ALWAYS runs on the GPU; there is no CPU fallback in this library.
+//   * Every element type the reference's headers can express -- float, UQ32, Vector2 / Vector3 of
+//     either (vector.h:4-126, uq32.h:8-16) -- with a Vector2<float> velocity: HIP kernels inside
+//     libsfl_hip.so, reached from any C++ compiler through libsfl_dropin.so.  The sketch's two
+//     instantiations (Vector2<float>, ino:253; Vector3<UQ32>, ino:282) take the tuned tile kernels.
+//   * Any OTHER element or velocity component type (a caller's own struct with the operators sample()
+//     needs): when this header is compiled by hipcc, a kernel is instantiated from the templates below
+//     (advect_device for device arrays; advect() itself stages host arrays).  A plain C++ compiler cannot
+//     build device code for a type it has never seen: there the call is rejected at compile time.
 // next_p must not alias p; p may alias vel (self-advection).  Link with libsfl_dropin.so.
 //
 // The reference's header also exposes its per-POINT helpers to every includer (advect.h:10-72):
@@ -20,6 +25,8 @@
 #define SFL_ADVECT_H
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -32,7 +39,19 @@ void advect_vec2f(Vector2<float> *next_p, Vector2<float> *p, Vector2<float> *vel
                   int dim_y, float dt, bool no_slip);
 void advect_vec3uq32(Vector3<UQ32> *next_p, Vector3<UQ32> *p, Vector2<float> *vel, int dim_x,
                      int dim_y, float dt, bool no_slip);
+// element = `channels` consecutive 32-bit channels, uq32 ? UQ32 raw : float (sfl_host_advect_channels)
+void advect_channels(void *next_p, void *p, Vector2<float> *vel, int dim_x, int dim_y, float dt, bool no_slip,
+                     int channels, bool uq32);
 }  // namespace sfl_dropin
+
+// Element types with kernels inside the library: channels (0 = none) and channel kind.
+template <class T> struct sfl_element { static constexpr int channels = 0; static constexpr bool uq32 = false; };
+template <> struct sfl_element<float> { static constexpr int channels = 1; static constexpr bool uq32 = false; };
+template <> struct sfl_element<UQ32> { static constexpr int channels = 1; static constexpr bool uq32 = true; };
+template <> struct sfl_element<Vector2<float>> { static constexpr int channels = 2; static constexpr bool uq32 = false; };
+template <> struct sfl_element<Vector2<UQ32>> { static constexpr int channels = 2; static constexpr bool uq32 = true; };
+template <> struct sfl_element<Vector3<float>> { static constexpr int channels = 3; static constexpr bool uq32 = false; };
+template <> struct sfl_element<Vector3<UQ32>> { static constexpr int channels = 3; static constexpr bool uq32 = true; };
 
 // ---- per-point helpers (advect.h:10-72) -------------------------------------------------------
 // what T becomes when scaled by a float: float stays float, Vector<anything> -> Vector<float>
@@ -99,19 +118,79 @@ SFL_XPU static T sample(T *p, float i, float j, int dim_x, int dim_y, bool no_sl
     return weight * on_wall;
 }
 
+#if defined(__HIPCC__)
+// advect() for ANY element / velocity type, instantiated from the caller's own T by hipcc: one thread per
+// cell, the header's own sample() (so exactly the arithmetic a host loop over sample() would do).
+template <class T, class U>
+__global__ void sfl_advect_any_kernel(T *next_p, T *p, const Vector2<U> *vel, int dim_x, int dim_y, float dt,
+                                      bool no_slip)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= dim_x || j >= dim_y) return;
+    const int ij = index(i, j, dim_x);
+    const Vector2<float> source = Vector2<float>(i, j) - vel[ij] * dt;   // advect.h:81
+    next_p[ij] = sample(p, source.x, source.y, dim_x, dim_y, no_slip);
+}
+
+// DEVICE arrays; asynchronous on `stream`.
+template <class T, class U>
+inline hipError_t advect_device(T *next_p, T *p, Vector2<U> *vel, int dim_x, int dim_y, float dt, bool no_slip,
+                                hipStream_t stream = nullptr)
+{
+    const dim3 block(64, 4), grid((dim_x + 63) / 64, (dim_y + 3) / 4);
+    sfl_advect_any_kernel<T, U><<<grid, block, 0, stream>>>(next_p, p, vel, dim_x, dim_y, dt, no_slip);
+    return hipGetLastError();
+}
+
+namespace sfl_detail {
+// host arrays of a type without a kernel in the library: stage, run the instantiated kernel, fetch; loud on failure
+template <class T, class U>
+inline void advect_staged(T *next_p, T *p, Vector2<U> *vel, int dim_x, int dim_y, float dt, bool no_slip)
+{
+    const size_t n = (size_t)dim_x * dim_y;
+    T *d_next = nullptr, *d_p = nullptr;
+    Vector2<U> *d_vel = nullptr;
+    auto must = [](hipError_t e, const char *what) {
+        if (e == hipSuccess) return;
+        fprintf(stderr, "sfl: advect<T> (%s) failed: %s\n", what, hipGetErrorString(e));
+        abort();
+    };
+    must(hipMalloc(reinterpret_cast<void **>(&d_next), n * sizeof(T)), "hipMalloc");
+    must(hipMalloc(reinterpret_cast<void **>(&d_p), n * sizeof(T)), "hipMalloc");
+    must(hipMalloc(reinterpret_cast<void **>(&d_vel), n * sizeof(Vector2<U>)), "hipMalloc");
+    must(hipMemcpy(d_p, p, n * sizeof(T), hipMemcpyHostToDevice), "upload");
+    must(hipMemcpy(d_vel, vel, n * sizeof(Vector2<U>), hipMemcpyHostToDevice), "upload");
+    must(advect_device(d_next, d_p, d_vel, dim_x, dim_y, dt, no_slip), "launch");
+    must(hipMemcpy(next_p, d_next, n * sizeof(T), hipMemcpyDeviceToHost), "download");
+    (void)hipFree(d_next);
+    (void)hipFree(d_p);
+    (void)hipFree(d_vel);
+}
+}  // namespace sfl_detail
+#endif  // __HIPCC__
+
 template <class T, class U>
 void advect(T *next_p, T *p, Vector2<U> *vel, int dim_x, int dim_y, float dt, bool no_slip)
 {
-    constexpr bool velocity_field = std::is_same<T, Vector2<float>>::value;
-    constexpr bool dye_field = std::is_same<T, Vector3<UQ32>>::value;
-    static_assert(std::is_same<U, float>::value, "advect: the velocity field must be Vector2<float>");
-    static_assert(velocity_field || dye_field,
-                  "advect: GPU kernels exist for T = Vector2<float> and T = Vector3<UQ32> "
-                  "(the instantiations of the sketch); other element types are not supported");
-    if constexpr (velocity_field)
+    constexpr bool in_library = sfl_element<T>::channels > 0 && std::is_same<U, float>::value;
+    if constexpr (std::is_same<T, Vector2<float>>::value && in_library)
         sfl_dropin::advect_vec2f(next_p, p, vel, dim_x, dim_y, dt, no_slip);
-    else
+    else if constexpr (std::is_same<T, Vector3<UQ32>>::value && in_library)
         sfl_dropin::advect_vec3uq32(next_p, p, vel, dim_x, dim_y, dt, no_slip);
+    else if constexpr (in_library)
+        sfl_dropin::advect_channels(next_p, p, vel, dim_x, dim_y, dt, no_slip, sfl_element<T>::channels,
+                                    sfl_element<T>::uq32);
+    else {
+#if defined(__HIPCC__)
+        sfl_detail::advect_staged(next_p, p, vel, dim_x, dim_y, dt, no_slip);
+#else
+        static_assert(in_library,
+                      "advect: the library holds GPU kernels for float, UQ32 and Vector2 / Vector3 of either, "
+                      "advected by a Vector2<float> velocity; for any other element or velocity type compile the "
+                      "caller with hipcc (the kernel is then instantiated from this header) -- there is no CPU "
+                      "fallback");
+#endif
+    }
 }
 
 #endif  // SFL_ADVECT_H

@@ -10,6 +10,7 @@
 #define SFL_VECTOR_H
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define SFL_XPU __host__ __device__
 #else
 #define SFL_XPU

@@ -64,6 +64,9 @@ class CpuPath:
         self._step.restype = C.c_int
         for f in (self._adv2, self._adv3, self._div, self._grad, self._pois):
             f.restype = None
+        self._advc = g("advect_channels")
+        self._advc.argtypes = [C.c_void_p, C.c_void_p, _F, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        self._advc.restype = C.c_int if prefix == "ref_" else None
 
     @staticmethod
     def _dims(a: np.ndarray):
@@ -79,6 +82,18 @@ class CpuPath:
         dim_x, dim_y = self._dims(vel)
         out = np.empty_like(p)
         self._adv3(_up(out), _up(p), _fp(vel), dim_x, dim_y, dt, int(no_slip))
+        return out
+
+    def advect_channels(self, p, vel, dt, no_slip):
+        """advect<T, float> for T = float / UQ32 / Vector2 / Vector3 of either: `p` is float32 or uint32 (UQ32 raw)
+        of shape [dim_y, dim_x] (scalar) or [dim_y, dim_x, 2 | 3]."""
+        dim_x, dim_y = self._dims(vel)
+        assert p.dtype in (np.float32, np.uint32) and p.flags.c_contiguous and p.shape[:2] == vel.shape[:2]
+        channels = 1 if p.ndim == 2 else int(p.shape[2])
+        out = np.empty_like(p)
+        rc = self._advc(out.ctypes.data, p.ctypes.data, _fp(vel), dim_x, dim_y, dt, int(no_slip), channels,
+                        1 if p.dtype == np.uint32 else 0)
+        assert not rc
         return out
 
     def divergence(self, v, dx=1.0):

@@ -40,6 +40,28 @@ REF_API void ref_advect_vec3uq32(uint32_t *next_p, uint32_t *p, float *vel, int 
            reinterpret_cast<Vector2<float> *>(vel), dim_x, dim_y, dt, no_slip != 0);
 }
 
+// advect<T, float> for every element type the reference's headers can express (channels x kind as in
+// include/sfl.h: kind 0 = float channels, 1 = UQ32 channels); returns 0, or -1 for a combination that is none
+template <class T>
+static void advect_as(void *next_p, void *p, float *vel, int dim_x, int dim_y, float dt, int no_slip)
+{
+    advect(static_cast<T *>(next_p), static_cast<T *>(p), reinterpret_cast<Vector2<float> *>(vel), dim_x, dim_y, dt,
+           no_slip != 0);
+}
+REF_API int ref_advect_channels(void *next_p, void *p, float *vel, int dim_x, int dim_y, float dt, int no_slip,
+                                int channels, int kind)
+{
+    switch (channels * 2 + (kind ? 1 : 0)) {
+        case 2: advect_as<float>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+        case 3: advect_as<UQ32>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+        case 4: advect_as<Vector2<float>>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+        case 5: advect_as<Vector2<UQ32>>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+        case 6: advect_as<Vector3<float>>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+        case 7: advect_as<Vector3<UQ32>>(next_p, p, vel, dim_x, dim_y, dt, no_slip); return 0;
+    }
+    return -1;
+}
+
 REF_API void ref_divergence(float *div, float *v, int dim_x, int dim_y, float dx)
 {
     calculate_divergence(div, reinterpret_cast<Vector2<float> *>(v), dim_x, dim_y, dx);

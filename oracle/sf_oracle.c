@@ -12,6 +12,7 @@
  *   orc_advect_vec2f / orc_advect_vec3uq32   advect.h:74-85, sample advect.h:24-72,
  *                                            lerp/bilinear advect.h:13-22,
  *                                            element types vector.h:4-126, uq32.h:8-16
+ *   orc_advect_channels                      advect<T,float> for T = float, UQ32, Vector2 / Vector3 of either
  *   orc_divergence                           finitediff.cpp:9-39 via operations.h:11-38
  *   orc_subtract_gradient                    finitediff.cpp:41-82
  *   orc_poisson_solve                        poisson.cpp:14-125
@@ -207,6 +208,73 @@ ORC_API void orc_advect_vec3uq32(uint32_t *next_p, const uint32_t *p, const floa
             float sx = (float)i - vel[2 * cell] * dt;
             float sy = (float)j - vel[2 * cell + 1] * dt;
             sample_vec3uq(p, sx, sy, dim_x, dim_y, no_slip, next_p + 3 * cell);
+        }
+    }
+}
+
+/* advect<T, float> (advect.h:74-85) for every element type the reference's headers can express:
+ * `channels` (1..3) consecutive 32-bit channels, all float (kind 0: float, Vector2<float>,
+ * Vector3<float>) or all UQ32 raw (kind 1: UQ32, Vector2<UQ32>, Vector3<UQ32>).  sample()
+ * (advect.h:24-72) is written against T's operators, which act channel by channel
+ * (vector.h:23-61, :83-126); TPromoted<T> has float channels (advect.h:10-11) and converting
+ * back narrows each channel on its own (uq32.h:13).  Same narrowing points as sample_vec3uq.   */
+static float chan_widen(uint32_t bits, int uq)
+{
+    float f;
+    if (uq) return uq32_to_float(bits);
+    memcpy(&f, &bits, 4);
+    return f;
+}
+static uint32_t chan_narrow(float x, int uq)
+{
+    uint32_t bits;
+    if (uq) return uq32_from_float(x);
+    memcpy(&bits, &x, 4);
+    return bits;
+}
+static void sample_channels(const uint32_t *p, float si, float sj, int dim_x, int dim_y, int no_slip,
+                            int nc, int uq, uint32_t *out)
+{
+    src_pos s = classify(si, sj, dim_x, dim_y);
+    int k;
+    if (!s.x_oob && !s.y_oob) {                      /* advect.h:37-42 */
+        const uint32_t *t = p + nc * ((long)dim_x * s.cj + s.ci);
+        const uint32_t *u = t + nc * (long)dim_x;
+        for (k = 0; k < nc; ++k) {
+            float lo = mix1(s.dj, chan_widen(t[k], uq), chan_widen(u[k], uq));
+            float hi = mix1(s.dj, chan_widen(t[nc + k], uq), chan_widen(u[nc + k], uq));
+            out[k] = chan_narrow(mix1(s.di, lo, hi), uq);
+        }
+        return;
+    }
+    if (s.x_oob && s.y_oob) {                        /* advect.h:46-48: the corner texel as stored */
+        const uint32_t *t = p + nc * ((long)dim_x * (s.y_under ? 0 : dim_y - 1) + (s.x_under ? 0 : dim_x - 1));
+        for (k = 0; k < nc; ++k) out[k] = t[k];
+    } else if (s.x_oob) {                            /* advect.h:49-51 */
+        const uint32_t *t = p + nc * ((long)dim_x * s.cj + (s.x_under ? 0 : dim_x - 1));
+        const uint32_t *u = t + nc * (long)dim_x;
+        for (k = 0; k < nc; ++k) out[k] = chan_narrow(mix1(s.dj, chan_widen(t[k], uq), chan_widen(u[k], uq)), uq);
+    } else {                                         /* advect.h:52-55 */
+        const uint32_t *t = p + nc * ((long)dim_x * (s.y_under ? 0 : dim_y - 1) + s.ci);
+        for (k = 0; k < nc; ++k) out[k] = chan_narrow(mix1(s.di, chan_widen(t[k], uq), chan_widen(t[nc + k], uq)), uq);
+    }
+    if (no_slip) {                                   /* advect.h:61-71 */
+        float f = wall_discount(&s, si, sj, dim_x, dim_y);
+        for (k = 0; k < nc; ++k) out[k] = chan_narrow(f * chan_widen(out[k], uq), uq);
+    }
+}
+
+ORC_API void orc_advect_channels(void *next_p, const void *p, const float *vel, int dim_x, int dim_y,
+                                 float dt, int no_slip, int channels, int kind)
+{
+    int i, j;
+    for (j = 0; j < dim_y; ++j) {
+        for (i = 0; i < dim_x; ++i) {
+            long cell = (long)dim_x * j + i;
+            float sx = (float)i - vel[2 * cell] * dt;
+            float sy = (float)j - vel[2 * cell + 1] * dt;
+            sample_channels((const uint32_t *)p, sx, sy, dim_x, dim_y, no_slip, channels, kind,
+                            (uint32_t *)next_p + channels * cell);
         }
     }
 }

@@ -12,6 +12,7 @@ fixtures are pure data (inputs + expected outputs); no reference source is store
 Files (np.savez_compressed):
   step_<dimx>x<dimy>_i<iters>.npz   inputs v0, c0 (LCG recipe of SURVEY.md 8c) and, for each of
                                     `nsteps` sim steps, v / div / p / colour after the step
+  advc_<dimx>x<dimy>.npz            advect<T, float> for T = float, UQ32, Vector2<UQ32>, Vector3<float>, both no_slip
   ops_<dimx>x<dimy>.npz             per-operator cases on numpy-RNG inputs, incl. both no_slip
                                     values for both advect instantiations, dx != 1, omega != 1.96
 """
@@ -76,6 +77,27 @@ def main():
         np.savez_compressed(path, **out)
         print("wrote", os.path.relpath(path), os.path.getsize(path), "bytes")
 
+
+    # advect<T, float> for the element types other than the sketch's two: float, UQ32, Vector2<UQ32>, Vector3<float>
+    # (the reference's own template instantiations, oracle/ref_shim.cpp)
+    for dim_x, dim_y in CHANNEL_SHAPES:
+        rng = np.random.default_rng(77 * dim_x + dim_y)
+        v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * 70).astype(np.float32)
+        out = {"v": v, "dt": DT}
+        for channels, uq in CHANNEL_TYPES:
+            shape = (dim_y, dim_x) if channels == 1 else (dim_y, dim_x, channels)
+            q = rng.integers(0, 2 ** 31, shape, dtype=np.uint32) if uq else (rng.standard_normal(shape) * 9).astype(np.float32)
+            tag = f"c{channels}{'u' if uq else 'f'}"
+            out[f"in_{tag}"] = q
+            for ns in (0, 1):
+                out[f"out_{tag}_ns{ns}"] = ref.advect_channels(q, v, DT, bool(ns))
+        path = os.path.join(HERE, f"advc_{dim_x}x{dim_y}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", os.path.relpath(path), os.path.getsize(path), "bytes")
+
+
+CHANNEL_SHAPES = [(2, 2), (5, 4), (33, 17), (61, 81)]
+CHANNEL_TYPES = [(1, False), (1, True), (2, True), (3, False)]
 
 if __name__ == "__main__":
     main()

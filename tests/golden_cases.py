@@ -64,6 +64,25 @@ def ops_files():
     return sorted(glob.glob(os.path.join(GOLDEN, "ops_*.npz")))
 
 
+def channel_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "advc_*.npz")))
+
+
+def check_channels(impl, path):
+    """advect<T, float> for the element types besides the sketch's two (fixture written by the reference)."""
+    z = np.load(path)
+    tag = os.path.basename(path)
+    n = 0
+    for key in z.files:
+        if not key.startswith("in_"):
+            continue
+        for ns in (0, 1):
+            assert_bit_equal(impl.advect_channels(z[key], z["v"], z["dt"], bool(ns)), z[f"out_{key[3:]}_ns{ns}"],
+                             f"{tag} {key[3:]} ns{ns}")
+            n += 1
+    assert n == 8
+
+
 def check_steps(impl, path):
     z = np.load(path)
     dim_x, dim_y, iters, nsteps = (int(x) for x in z["meta"])

@@ -61,6 +61,55 @@ def test_known_answer_hashes(hip, oracle, case):
         assert (h(v), h(d), h(p), h(c)) == want
 
 
+@pytest.mark.parametrize("path", G.channel_files(), ids=lambda p: p.split("/")[-1])
+def test_generic_advect_matches_golden(hip, path):
+    """advect<T, float> for T = float, UQ32, Vector2<UQ32>, Vector3<float> against fixtures the reference wrote."""
+    G.check_channels(hip, path)
+
+
+@pytest.mark.parametrize("dim_x,dim_y", [(2, 2), (3, 7), (64, 4), (65, 5), (257, 100), (1000, 333), (2048, 1030)])
+@pytest.mark.parametrize("channels,uq", [(1, False), (1, True), (2, False), (2, True), (3, False), (3, True)])
+def test_generic_advect_every_element_type_vs_oracle(hip, oracle, dim_x, dim_y, channels, uq):
+    """Every element type the reference's headers can express (advect.h:74-85 over vector.h / uq32.h), slow and fast
+    velocity fields, both wall rules; the sketch's two types take the tile kernels through the same entry point."""
+    rng = np.random.default_rng(dim_x * 3 + dim_y + 10 * channels + uq)
+    shape = (dim_y, dim_x) if channels == 1 else (dim_y, dim_x, channels)
+    for vamp in (0.0, 40.0, 900.0):
+        v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * vamp).astype(np.float32)
+        q = rng.integers(0, 2 ** 31, shape, dtype=np.uint32) if uq else (rng.standard_normal(shape) * 20).astype(np.float32)
+        for no_slip in (True, False):
+            assert_bit_equal(hip.advect_channels(q, v, DT, no_slip), oracle.advect_channels(q, v, DT, no_slip),
+                             f"{channels} x {'uq32' if uq else 'f32'}, vamp {vamp}, no_slip {no_slip}")
+
+
+def test_generic_advect_rejects_what_it_cannot_be(sfl, hip):
+    v = np.zeros((4, 4, 2), np.float32)
+    with pytest.raises(sfl.SflError):
+        hip.advect_channels(np.zeros((4, 4, 4), np.float32), v, DT, True)       # four channels: no such reference type
+    with pytest.raises(TypeError):
+        hip.advect_channels(np.zeros((4, 4), np.float64), v, DT, True)
+
+
+def test_external_device_field_is_advected_with_the_resident_velocity(sfl, oracle):
+    """sfl_advect_external: a scalar of the caller's, resident on the device (here: the context's own divergence /
+    pressure buffers stand in for it), carried by the context's velocity; whole-domain contexts only."""
+    dim_x, dim_y = 200, 120
+    v, _, t = random_fields(dim_x, dim_y, 21, 70.0)
+    with sfl.Solver(dim_x, dim_y) as s:
+        s.upload(sfl.capi.FIELD_VELOCITY, v)
+        s.upload(sfl.capi.FIELD_DIVERGENCE, t)
+        s.upload(sfl.capi.FIELD_PRESSURE, np.zeros_like(t))
+        src, dst = s.device_ptr(sfl.capi.FIELD_DIVERGENCE), s.device_ptr(sfl.capi.FIELD_PRESSURE)
+        s.advect_external(dst, src, 1, sfl.capi.CHANNEL_F32, DT, False)
+        s.synchronize()
+        assert_bit_equal(s.download(sfl.capi.FIELD_PRESSURE), oracle.advect_channels(t, v, DT, False), "external scalar")
+        with pytest.raises(sfl.SflError):
+            s.advect_external(src, src, 1, sfl.capi.CHANNEL_F32, DT, False)     # next_p == p
+    with sfl.Solver(dim_x, dim_y, rank=0, nranks=2) as slab:
+        with pytest.raises(sfl.SflError):
+            slab.advect_external(1, 2, 1, 0, DT, False)
+
+
 SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (64, 48), (127, 33), (128, 64),
           (130, 70), (257, 100), (300, 41), (512, 96)]
 

@@ -17,8 +17,13 @@ def test_oracle_ops_match_golden(oracle, path):
     G.check_ops(oracle, path)
 
 
+@pytest.mark.parametrize("path", G.channel_files(), ids=lambda p: p.split("/")[-1])
+def test_oracle_generic_advect_matches_golden(oracle, path):
+    G.check_channels(oracle, path)
+
+
 def test_fixture_inventory():
-    assert len(G.step_files()) >= 7 and len(G.ops_files()) >= 6
+    assert len(G.step_files()) >= 7 and len(G.ops_files()) >= 6 and len(G.channel_files()) >= 4
 
 
 def test_lcg_recipe_and_hash_helpers_agree(oracle):

@@ -38,6 +38,34 @@ def test_advect_vec3uq32(oracle, reference, dim_x, dim_y, no_slip):
                          reference.advect_vec3uq32(c, v, DT, no_slip), "dye advection")
 
 
+def channel_field(rng, dim_x, dim_y, channels, uq, cmax=2 ** 31):
+    """A field of one of the element types the reference's headers can express (float / UQ32, x 1..3)."""
+    shape = (dim_y, dim_x) if channels == 1 else (dim_y, dim_x, channels)
+    if uq:
+        return rng.integers(0, cmax, shape, dtype=np.uint32)
+    return (rng.standard_normal(shape) * 50).astype(np.float32)
+
+
+@pytest.mark.parametrize("dim_x,dim_y", SHAPES)
+@pytest.mark.parametrize("channels,uq", [(1, False), (1, True), (2, False), (2, True), (3, False), (3, True)])
+def test_advect_every_element_type(oracle, reference, dim_x, dim_y, channels, uq):
+    """advect<T, float> (advect.h:74-85) for T = float, UQ32, Vector2 / Vector3 of either: the oracle's
+    channel-wise restatement against the reference's own template instantiations."""
+    rng = np.random.default_rng(dim_x * 131 + dim_y * 7 + channels * 2 + uq)
+    for vamp, cmax in [(100.0, 2 ** 31), (5.0, 2 ** 24 + 7), (1000.0, 1000), (0.0, 2 ** 31)]:
+        v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * vamp).astype(np.float32)
+        q = channel_field(rng, dim_x, dim_y, channels, uq, cmax)
+        for no_slip in (True, False):
+            assert_bit_equal(oracle.advect_channels(q, v, DT, no_slip), reference.advect_channels(q, v, DT, no_slip),
+                             f"{channels} x {'uq32' if uq else 'f32'}, no_slip {no_slip}")
+    # the two instantiations of the sketch through the generic entry = through their own
+    v, c, _ = random_fields(dim_x, dim_y, 3, 60.0)
+    if channels == 2 and not uq:
+        assert_bit_equal(oracle.advect_channels(v, v, DT, True), oracle.advect_vec2f(v, v, DT, True), "vec2f")
+    if channels == 3 and uq:
+        assert_bit_equal(oracle.advect_channels(c, v, DT, False), oracle.advect_vec3uq32(c, v, DT, False), "vec3uq32")
+
+
 @pytest.mark.parametrize("dim_x,dim_y", SHAPES)
 @pytest.mark.parametrize("dx", [1.0, 0.5, 3.0])
 def test_divergence_and_gradient(oracle, reference, dim_x, dim_y, dx):

@@ -20,3 +20,6 @@ PY
   done
 done
 bash tools/r04/wire_curve.sh
+# per-wave trace of the thin share (CSV: tile, start / end on both clocks, hardware slot, XCD, path) for the balance study
+./tools/sor_clock_probe_ns10 8192 1024 40 0 $O/probe_ns10_slab1024.csv > $O/probe_ns10_slab1024.txt 2>&1
+cat $O/probe_ns10_slab1024.txt
