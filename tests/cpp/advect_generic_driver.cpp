@@ -55,7 +55,11 @@ int main()
         const int dim_x = s[0], dim_y = s[1], n = dim_x * dim_y;
         std::vector<Vector2<float>> vel(n);
         lcg_state = 4711u + 977u * dim_x + dim_y;
-        for (int k = 0; k < n; ++k) vel[k] = Vector2<float>(next_unit() * 10.0f, next_unit() * 10.0f);  // up to 3 cells
+        // (draws are sequenced by statements: the order in which a compiler evaluates call arguments is its own)
+        for (int k = 0; k < n; ++k) {
+            const float vx = next_unit() * 10.0f, vy = next_unit() * 10.0f;   // up to 3 cells per step
+            vel[k] = Vector2<float>(vx, vy);
+        }
         std::printf("# %d x %d\n", dim_x, dim_y);
         run<float, float>("float", 1, dim_x, dim_y, vel, [] { return next_unit() * 4.0f; });
         run<UQ32, float>("UQ32", 2, dim_x, dim_y, vel, [] { UQ32 c; c.raw = next_u32() >> 1; return c; });
@@ -65,11 +69,15 @@ int main()
             c.y.raw = next_u32() >> 9;   // small raws too: exact in float
             return c;
         });
-        run<Vector3<float>, float>("Vector3<float>", 4, dim_x, dim_y, vel,
-                                   [] { return Vector3<float>(next_unit(), next_unit() * 100.0f, next_unit() * 1e-3f); });
+        run<Vector3<float>, float>("Vector3<float>", 4, dim_x, dim_y, vel, [] {
+            const float a = next_unit(), b = next_unit() * 100.0f, c = next_unit() * 1e-3f;
+            return Vector3<float>(a, b, c);
+        });
 #ifdef DRIVER_ANY_TYPE
-        run<Vector2<double>, float>("Vector2<double>", 5, dim_x, dim_y, vel,
-                                    [] { return Vector2<double>(double(next_unit()) / 3.0, double(next_unit()) * 7.0); });
+        run<Vector2<double>, float>("Vector2<double>", 5, dim_x, dim_y, vel, [] {
+            const double a = double(next_unit()) / 3.0, b = double(next_unit()) * 7.0;
+            return Vector2<double>(a, b);
+        });
         std::vector<Vector2<double>> vel_d(n);
         for (int k = 0; k < n; ++k) vel_d[k] = Vector2<double>(double(vel[k].x) + 1e-9, double(vel[k].y) - 1e-9);
         run<float, double>("float|Vector2<double> velocity", 6, dim_x, dim_y, vel_d, [] { return next_unit() * 4.0f; });

@@ -167,22 +167,77 @@ def test_reference_style_caller_runs_on_gpu(tmp_path, oracle, dim_x, dim_y, iter
         assert_bit_equal(a, b, f"drop-in caller: {name}")
 
 
-@pytest.mark.gpu
-def test_domain_for_each_runs_user_expressions_on_the_device(tmp_path, oracle):
-    """SURVEY 8f N4: user safe/fast functors through sfl/operations.h::domain_for_each."""
+def _build_domain_for_each(tmp_path):
     exe = tmp_path / "dfe"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17",
                     "-ffp-contract=off", "-I", INC, os.path.join(CPP, "domain_for_each_test.hip"),
                     "-o", str(exe)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return exe
+
+
+def test_domain_for_each_caller_builds(tmp_path):
+    _build_domain_for_each(tmp_path)
+
+
+@pytest.mark.gpu
+def test_domain_for_each_runs_user_expressions_on_the_device(tmp_path, oracle):
+    """SURVEY 8f N4: user safe/fast functors through sfl/operations.h::domain_for_each (out of place, T != U)."""
+    exe = _build_domain_for_each(tmp_path)
     dim_x, dim_y = 97, 45
     v = (np.random.default_rng(1).uniform(-1, 1, (dim_y, dim_x, 2)) * 30).astype(np.float32)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
         f.write(struct.pack("2i", dim_x, dim_y))
         f.write(v.tobytes())
-    subprocess.run([str(exe), str(fin), str(fout)], check=True)
+    subprocess.run([str(exe), "div", str(fin), str(fout)], check=True)
     got = np.fromfile(fout, np.float32).reshape(dim_y, dim_x)
     assert_bit_equal(got, oracle.divergence(v, 1.0), "domain_for_each divergence")
+
+
+@pytest.mark.gpu
+def test_domain_for_each_in_place_leaves_the_reference_orders_bits(tmp_path):
+    """operations.h:11-38 allows wrt == rd (finitediff.cpp:80 uses it).  Order-SENSITIVE expressions -- every cell reads
+    its four neighbours and overwrites the centre -- run in place on the device and must leave exactly what the
+    reference's visiting order leaves: case A of tests/golden/domain_iter_reference.txt (written by the reference's own
+    operations.h), then larger grids against the host domain_iter of include/sfl (itself pinned to that fixture)."""
+    exe = _build_domain_for_each(tmp_path)
+    got = subprocess.run([str(exe), "inplace"], capture_output=True, text=True, check=True).stdout.splitlines()
+    want = [l for l in open(os.path.join(ROOT, "tests", "golden", "domain_iter_reference.txt")).read().splitlines()
+            if l.startswith("A ")]
+    strip_calls = lambda l: " ".join(t for t in l.split() if not t.startswith("calls="))
+    a_lines = [l for l in got if l.startswith("A ")]
+    assert len(a_lines) == len(want) == 6 and a_lines == [strip_calls(l) for l in want]
+    b_lines = [l for l in got if l.startswith("B ")]
+    assert len(b_lines) == 3 and all(l.endswith(" same") for l in b_lines), b_lines
+
+
+@pytest.mark.gpu
+def test_domain_for_each_pointwise_in_place_and_red_black(tmp_path, oracle):
+    """The two in-place uses the reference itself makes of its drivers, as USER functors on the device:
+    subtract_gradient's expressions over the velocity in place (finitediff.cpp:80; they read only the centre of the field
+    they rewrite: every cell at once), and the SOR expressions through the colour-split driver (poisson.cpp:14-61,
+    :121-124), both against the oracle."""
+    exe = _build_domain_for_each(tmp_path)
+    dim_x, dim_y, iters = 131, 77, 9
+    rng = np.random.default_rng(5)
+    v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * 30).astype(np.float32)
+    p = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("2i", dim_x, dim_y))
+        f.write(v.tobytes())
+        f.write(p.tobytes())
+    subprocess.run([str(exe), "pointwise", str(fin), str(fout)], check=True)
+    assert_bit_equal(np.fromfile(fout, np.float32).reshape(dim_y, dim_x, 2), oracle.subtract_gradient(v, p, 1.0),
+                     "in-place gradient subtraction by user functors")
+    for dx_, dy_ in ((dim_x, dim_y), (2, 2), (3, 2), (64, 5)):
+        d = rng.standard_normal((dy_, dx_)).astype(np.float32)
+        with open(fin, "wb") as f:
+            f.write(struct.pack("3i", dx_, dy_, iters))
+            f.write(d.tobytes())
+        subprocess.run([str(exe), "redblack", str(fin), str(fout)], check=True)
+        assert_bit_equal(np.fromfile(fout, np.float32).reshape(dy_, dx_), oracle.poisson_solve(d, 1.0, iters, np.float32(1.96)),
+                         f"red-black SOR by user functors {dx_}x{dy_}")
 
 
 @pytest.mark.gpu
