@@ -243,6 +243,9 @@ def parse_args(argv=None):
                     help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
+    ap.add_argument("--arrival-by-event", action="store_true",
+                    help="SFL_OPT_SOR_ARRIVAL = 0: the launch behind a halo waits for a cross-stream event instead of "
+                         "letting its cut-adjacent tiles poll the device-side arrival count (A/B)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
     ap.add_argument("--dry-run", action="store_true",
@@ -384,6 +387,8 @@ def run_rank(args):
         s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
     if args.no_overlap:
         s.set_option(capi.OPT_SOR_OVERLAP, 0)
+    if args.arrival_by_event:
+        s.set_option(capi.OPT_SOR_ARRIVAL, 0)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
                      (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
                      (capi.OPT_SOR_HALO, args.sor_halo), (capi.OPT_ADVECT_KERNEL, args.advect_kernel)):

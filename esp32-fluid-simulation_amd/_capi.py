@@ -19,6 +19,7 @@ OPT_ADVECT_KERNEL = 9
 OPT_FUSE_DIVERGENCE = 10
 OPT_SMALL_GRID = 11
 OPT_EMULATE_WIRE_US = 12
+OPT_SOR_ARRIVAL = 13
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128

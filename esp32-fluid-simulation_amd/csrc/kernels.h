@@ -109,10 +109,28 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 struct SorRows {
     int g_begin, g_end;
     int g2_begin, g2_end;
+    int urgent;   // 1: every wave of the launch runs at the top issue priority -- a small launch on the exchange
+                  // stream that the compute stream's resident launch is waiting for (the ghost rows behind a halo
+                  // message) must not queue up behind that launch's waves on the SIMDs they share
 };
+// Device-side halo arrival.  A launch may start BEFORE a halo message it depends on has arrived: its tiles whose
+// input rows all lie inside [own_lo, own_hi) -- rows no message writes -- run at once, the others (the tiles next
+// to a cut) first wait, inside the launch, until *flag has reached `epoch` (signed distance: the word only
+// counts up, launch_signal_arrival), then make the arrived rows visible to their CU (agent-scope acquire).  A wait
+// that lasts longer than kHaloWaitTimeoutUs gives up and raises *timed_out (results are then wrong: the host turns
+// the word into an error): a lost message must never hang the GPU.  flag == nullptr: nobody waits.
+struct HaloWait {
+    const int *flag;
+    int *timed_out;
+    int epoch;
+    int own_lo, own_hi;
+};
+constexpr int kHaloWaitTimeoutUs = 2000000;
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int sweep);
+                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait = nullptr);
+// *flag = value, visible to every CU (stream-ordered behind the message / the kernels that relaxed it)
+hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value);
 
 // ---- small grids: one workgroup, fields in LDS (small_grid.hip) -------------------------------------
 // WHOLE-DOMAIN arrays of dim_x * dim_y <= kSmallGridMaxCells cells (16 B of LDS per cell: 96 KB of the CU's 160;
@@ -146,6 +164,11 @@ hipError_t launch_zero_rows(hipStream_t s, float *f, Slab g, int g_begin, int g_
 // [g_begin, g_end).  cells = {i, j} pairs (global), device arrays.
 hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
                                const int *cells_ij, const float *vel_xy, int n);
+
+// Two row bands of a halo exchange between arrays of ONE device (virtual ranks, the emulated rank) in ONE launch:
+// dst_a <- src_a and dst_b <- src_b, `bytes` each (a null destination is skipped).  The runtime's own copy takes
+// 6 - 7 us per 0.85 MB band and runs its two copies one after the other.
+hipError_t launch_copy_bands(hipStream_t s, void *dst_a, const void *src_a, void *dst_b, const void *src_b, size_t bytes);
 
 // Measurement aid: one wave idling for `us` microseconds (the emulated wire of sfl_comm_emulate).
 hipError_t launch_spin_us(hipStream_t s, int us);

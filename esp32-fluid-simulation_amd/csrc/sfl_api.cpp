@@ -99,7 +99,10 @@ struct sfl_context {
     float *sor_block = nullptr;
     float *div = nullptr;
     float *p = nullptr, *p_alt = nullptr;  // p = current pressure, p_alt = ping-pong partner
-    int *halo_flag = nullptr;
+    int *halo_flag = nullptr;      // device words: [0] a back-trace left a fixed advection halo
+    int *d_arrival = nullptr;      // [1] halo messages arrived (and relaxed) so far: what cut-adjacent tiles poll inside a
+                                   //     launch (kernels.h HaloWait); [2] such a wait timed out
+    int arrival_epoch = 0;         // the last value queued for [1]
 
     // queued point forces (ino:264-269)
     std::vector<int> force_cells;
@@ -147,7 +150,7 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1;
 
     ncclComm_t comm = nullptr;
     bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
@@ -285,18 +288,14 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
     };
 
     if (any->group) {  // in-process transport: all virtual ranks share one stream
-        for (sfl_context *c : peers) {
+        for (sfl_context *c : peers) {   // both bands of a slab in one launch
             SFL_TRY(use_device(c));
-            if (c->rank > 0) {
-                sfl_context *lo = peers[c->rank - 1];
-                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - skip - rows), row_ptr(lo, lo->g1 - skip - rows), bytes,
-                                       hipMemcpyDeviceToDevice, on ? on : c->stream));
-            }
-            if (c->rank < c->nranks - 1) {
-                sfl_context *hi = peers[c->rank + 1];
-                HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1 + skip), row_ptr(hi, hi->g0 + skip), bytes,
-                                       hipMemcpyDeviceToDevice, on ? on : c->stream));
-            }
+            sfl_context *lo = c->rank > 0 ? peers[c->rank - 1] : nullptr;
+            sfl_context *hi = c->rank < c->nranks - 1 ? peers[c->rank + 1] : nullptr;
+            HIP_TRY(sfl::launch_copy_bands(on ? on : c->stream, lo ? row_ptr(c, c->g0 - skip - rows) : nullptr,
+                                           lo ? row_ptr(lo, lo->g1 - skip - rows) : nullptr,
+                                           hi ? row_ptr(c, c->g1 + skip) : nullptr, hi ? row_ptr(hi, hi->g0 + skip) : nullptr,
+                                           bytes));
         }
         return SFL_OK;
     }
@@ -309,12 +308,10 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         SFL_TRY(use_device(c));
         hipStream_t st = on ? on : c->stream;
         HIP_TRY(sfl::launch_spin_us(st, c->opt_emulate_wire_us));   // the wire a self-copy does not have (0: none)
-        if (c->rank > 0)
-            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g0 - skip - rows), row_ptr(c, c->g0 + skip), bytes,
-                                   hipMemcpyDeviceToDevice, st));
-        if (c->rank < c->nranks - 1)
-            HIP_TRY(hipMemcpyAsync(row_ptr(c, c->g1 + skip), row_ptr(c, c->g1 - skip - rows), bytes,
-                                   hipMemcpyDeviceToDevice, st));
+        const bool lo = c->rank > 0, hi = c->rank < c->nranks - 1;
+        HIP_TRY(sfl::launch_copy_bands(st, lo ? row_ptr(c, c->g0 - skip - rows) : nullptr, lo ? row_ptr(c, c->g0 + skip) : nullptr,
+                                       hi ? row_ptr(c, c->g1 + skip) : nullptr, hi ? row_ptr(c, c->g1 - skip - rows) : nullptr,
+                                       bytes));
         return SFL_OK;
     }
     if (!c->comm)
@@ -396,7 +393,7 @@ int effective_halo(const sfl_context *c, int fuse)
 // `in` / `out` = the step's input and output arrays (null: c->p / c->p_alt); `on` = stream (null: the compute stream)
 int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
                     int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const float *in = nullptr,
-                    float *out = nullptr)
+                    float *out = nullptr, const sfl::HaloWait *wait = nullptr, int urgent = 0)
 {
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
     if (!in) in = c->p;
@@ -408,9 +405,33 @@ int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParam
     // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
     const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
     HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, out, st.from_zero ? nullptr : in, c->div, c->geom,
-                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
-                                  prm, c->opt_sor_rows, sweep));
+                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end, urgent}, st.nsweeps, st.first_colour,
+                                  prm, c->opt_sor_rows, sweep, wait));
     return SFL_OK;
+}
+
+// Device-side halo arrival (SFL_OPT_SOR_ARRIVAL, kernels.h HaloWait).  The exchange stream counts a context's arrived
+// messages in a device word; the next launch on the compute stream is queued WITHOUT a cross-stream event and lets only
+// its cut-adjacent tiles wait for the count.
+int signal_arrival(const std::vector<sfl_context *> &peers, hipStream_t xstream)
+{
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        ++c->arrival_epoch;
+        HIP_TRY(sfl::launch_signal_arrival(xstream, c->d_arrival, c->arrival_epoch));
+    }
+    return SFL_OK;
+}
+
+sfl::HaloWait arrival_wait(const sfl_context *c)
+{
+    sfl::HaloWait w;
+    w.flag = c->d_arrival;
+    w.timed_out = c->d_arrival + 1;
+    w.epoch = c->arrival_epoch;
+    w.own_lo = c->rank > 0 ? c->g0 : -(1 << 30);                 // no cut on that side: nothing to wait for
+    w.own_hi = c->rank < c->nranks - 1 ? c->g1 : (1 << 30);
+    return w;
 }
 
 int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm)
@@ -545,6 +566,12 @@ int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context
 {
     bool pending = false;  // an exchange is in flight that the next launch's cut-adjacent rows need
     bool behind_early = false;  // ... an early one, with a launch queued behind it: the next launch needs all of it
+    // Device-side arrival (early-exchange plans): no event between the exchange stream and the launch that needs the
+    // halo -- that launch is queued at once and its cut-adjacent tiles poll the arrival count (`flagged` = the next
+    // launch on the compute stream carries the wait).  Every p exchange of such a plan is an early one; the classic
+    // branches below then only ever see the exchange of the right-hand side.
+    const bool by_flag = ctx->opt_sor_arrival && effective_halo(ctx, effective_fuse(ctx)) >= 2 * effective_fuse(ctx);
+    bool flagged = false;
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -564,16 +591,47 @@ int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context
                 const sfl_plan_step &st = progs[k][i + 1];
                 const int lo = c->rank > 0 ? c->g0 : st.g_begin;
                 const int hi = c->rank < c->nranks - 1 ? c->g1 : st.g_end;
-                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));                                      // compute stream
-                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream));     // behind the message
+                // (a launch that is itself the first after an earlier exchange -- a halo of exactly two launches --
+                // reads that exchange's ghost rows: its cut-adjacent tiles wait for them)
+                const sfl::HaloWait w = arrival_wait(c);
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi, 0, 0, nullptr, nullptr, nullptr, flagged ? &w : nullptr));  // compute stream
+                // behind the message, on the exchange stream -- urgent when the compute stream's next launch will be
+                // resident and waiting for it: its waves share the SIMDs with that launch's
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream, nullptr, nullptr, nullptr, by_flag));
             }
-            SFL_TRY(mark_arrived(peers, o));
+            flagged = false;
+            if (by_flag) {
+                SFL_TRY(signal_arrival(peers, o.xstream));
+                flagged = true;
+            } else {
+                SFL_TRY(mark_arrived(peers, o));
+                pending = behind_early = true;
+            }
             for (sfl_context *c : peers) {
                 std::swap(c->p, c->p_alt);
                 ++c->last_launches;
             }
-            pending = behind_early = true;
             ++i;  // the launch has been issued
+            continue;
+        }
+        if (by_flag && st0.kind == SFL_STEP_EXCHANGE && !pending) {
+            // (the right-hand side at the head of a solve) the message, then the arrival count; the launch that
+            // follows is issued whole, its cut-adjacent tiles wait inside it
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false));
+            SFL_TRY(signal_arrival(peers, o.xstream));
+            flagged = true;
+            continue;
+        }
+        if (flagged && st0.kind == SFL_STEP_SOR) {
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i];
+                const sfl::HaloWait w = arrival_wait(c);
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr, nullptr, nullptr, &w));
+                std::swap(c->p, c->p_alt);
+                ++c->last_launches;
+            }
+            flagged = false;
             continue;
         }
         if (st0.kind == SFL_STEP_EXCHANGE) {  // (classic p exchanges are started by the launch before them)
@@ -939,9 +997,10 @@ int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int ran
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
     void *flag = nullptr;
-    HIP_TRY(hipMalloc(&flag, sizeof(int)));
-    HIP_TRY(hipMemset(flag, 0, sizeof(int)));
+    HIP_TRY(hipMalloc(&flag, 4 * sizeof(int)));
+    HIP_TRY(hipMemset(flag, 0, 4 * sizeof(int)));
     c->halo_flag = static_cast<int *>(flag);
+    c->d_arrival = c->halo_flag + 1;
     *out = c.release();
     return SFL_OK;
 }
@@ -1036,6 +1095,9 @@ static int set_option_one(sfl_context *c, int option, int value)
             if (value < 0 || value > 10000) return fail(SFL_ERR_INVALID, "emulated wire delay must be 0..10000 us");
             c->opt_emulate_wire_us = value;
             return SFL_OK;
+        case SFL_OPT_SOR_ARRIVAL:
+            c->opt_sor_arrival = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -1083,6 +1145,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_FUSE_DIVERGENCE: *value = c->opt_fuse_divergence; return SFL_OK;
         case SFL_OPT_SMALL_GRID: *value = c->opt_small_grid; return SFL_OK;
         case SFL_OPT_EMULATE_WIRE_US: *value = c->opt_emulate_wire_us; return SFL_OK;
+        case SFL_OPT_SOR_ARRIVAL: *value = c->opt_sor_arrival; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -1114,7 +1177,7 @@ static void option_block(const sfl_context *c, int *b)
 {
     const int v[kOptionBlockInts] = {SFL_ABI_VERSION, c->dim_x, c->gdim_y, c->nranks, c->opt_sor_kernel, c->opt_sor_fuse,
                                      c->opt_sor_halo, c->opt_sor_overlap, c->opt_advect_halo, c->opt_fuse_projection,
-                                     c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, 0, 0, 0};
+                                     c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, c->opt_sor_arrival, 0, 0};
     memcpy(b, v, sizeof v);
 }
 
@@ -1241,6 +1304,7 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_advect_kernel = z->opt_advect_kernel;
         c->opt_fuse_divergence = z->opt_fuse_divergence;
         c->opt_small_grid = z->opt_small_grid;
+        c->opt_sor_arrival = z->opt_sor_arrival;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
@@ -2047,12 +2111,18 @@ int sfl_synchronize(sfl_context *ctx)
         SFL_TRY(use_device(c));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->nranks > 1) {
-            int flag = 0;
-            HIP_TRY(hipMemcpy(&flag, c->halo_flag, sizeof flag, hipMemcpyDeviceToHost));
-            if (flag) {
-                HIP_TRY(hipMemset(c->halo_flag, 0, sizeof flag));
+            int words[3] = {0, 0, 0};   // halo_flag, arrival count, a wait for it timed out
+            HIP_TRY(hipMemcpy(words, c->halo_flag, sizeof words, hipMemcpyDeviceToHost));
+            if (words[0]) {
+                HIP_TRY(hipMemset(c->halo_flag, 0, sizeof(int)));
                 rc = fail(SFL_ERR_HALO, "slab %d/%d: a back-trace left the %d-row advect halo; raise "
                           "SFL_OPT_ADVECT_HALO", c->rank, c->nranks, c->opt_advect_halo);
+            }
+            if (words[2]) {
+                HIP_TRY(hipMemset(c->halo_flag + 2, 0, sizeof(int)));
+                rc = fail(SFL_ERR_HIP, "slab %d/%d: tiles of a solve waited longer than %d s for a halo message (arrival "
+                          "count %d of %d): the pressure field is not valid", c->rank, c->nranks,
+                          sfl::kHaloWaitTimeoutUs / 1000000, words[1], c->arrival_epoch);
             }
         }
     }

@@ -135,6 +135,10 @@ struct WaveCommon {
     // 228 -> 217 us; profiles/r03_priority_rotation.txt).
     __device__ __forceinline__ void start_turns()
     {
+        if (prio_on == 2) {   // an urgent launch (SorRows::urgent): top priority from the first instruction, no turns
+            __builtin_amdgcn_s_setprio(3);
+            return;
+        }
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));  // wave slot on the SIMD
         prio_turn = (int)(hw % SFL_PRIO_LEVELS);
@@ -146,7 +150,7 @@ struct WaveCommon {
         // s_setprio takes an immediate: select it with scalar branches INSIDE one asm statement, so that the
         // straight-line trip stays straight-line for the compiler (a visible branch makes its wait-count pass
         // drain the loads in flight)
-        asm volatile("s_cmp_eq_u32 %1, 0\n\t"
+        asm volatile("s_cmp_lg_u32 %1, 1\n\t"
                      "s_cbranch_scc1 .Lsfl_pe_%=\n\t"
                      "s_cmp_lg_u32 %0, 0\n\t"
                      "s_cbranch_scc1 .Lsfl_p1_%=\n\t"
@@ -282,6 +286,103 @@ struct Lane2 : WaveCommon {
         }
     }
 
+#ifdef SFL_PROBE_COOP
+    // TIMING MOCK of cooperative tiles (tools/sor_clock_probe.hip -DSFL_PROBE_COOP; never in the product): the waves of a
+    // block would be neighbouring strips that overlap by one lane on each side and keep each other's edge lanes exact
+    // instead of letting NS columns per side go stale.  Per row every wave then (1) publishes the newest state of its two
+    // outermost exact lanes -- NS values each: one per row in flight -- to LDS, (2) meets its neighbours at a barrier (all
+    // cross-wave operands of row y were produced in row y - 1), (3) overwrites the state of its two ghost lanes with the
+    // neighbours' values: exec-masked LDS accesses, no vector-ALU instruction.  Here the values go round in the same way
+    // but between arbitrary lanes of the block, so the results are garbage; instruction mix, LDS traffic and the
+    // barrier are the real thing.  The tiling is NOT changed: compare the time per launch with the shipped kernel's and
+    // multiply by the tiles the scheme would save.
+    float *coop_pub, *coop_get;   // this lane's publish / pick-up word in the block's exchange area
+    bool coop_is_pub, coop_is_ghost;
+#if SFL_PROBE_COOP == 2
+    static __device__ __forceinline__ unsigned lds_addr(float *p)
+    {
+        return (unsigned)(size_t)(__attribute__((address_space(3))) float *)p;
+    }
+    // hand-scheduled flavour: ONE exec toggle around the NS publishing writes, ONE around the NS ghost-lane reads (which
+    // land directly in the state registers), no vector-ALU instruction at all
+    template <int NSW, int U, int K, class P>
+    __device__ __forceinline__ void coop_pair(P &pp, unsigned long long m_pub, unsigned long long m_get)
+    {
+        constexpr int RING = sor::ring_rows(NSW);
+        constexpr int par = U & 1;
+        constexpr int e0 = sor::wrapn(U - 1 - 4 * K, RING), e1 = sor::wrapn(U - 3 - 4 * K, RING);
+        constexpr int o0 = sor::wrapn(U - 2 - 4 * K, RING), o1 = sor::wrapn(U - 4 - 4 * K, RING);
+        constexpr int b = (par * NSW + 4 * K) * 32;
+        asm volatile("s_mov_b64 exec, %[m]\n\t"
+                     "ds_write_b32 %[a], %[v0] offset:%[f0]\n\t"
+                     "ds_write_b32 %[a], %[v1] offset:%[f1]\n\t"
+                     "ds_write_b32 %[a], %[v2] offset:%[f2]\n\t"
+                     "ds_write_b32 %[a], %[v3] offset:%[f3]\n\t"
+                     "s_mov_b64 exec, -1"
+                     :
+                     : [m] "s"(m_pub), [a] "v"(lds_addr(coop_pub)), [v0] "v"(pp.E[e0]), [v1] "v"(pp.E[e1]), [v2] "v"(pp.O[o0]),
+                       [v3] "v"(pp.O[o1]), [f0] "n"(b), [f1] "n"(b + 32), [f2] "n"(b + 64), [f3] "n"(b + 96)
+                     : "memory");
+    }
+    template <int NSW, int U, int K, class P>
+    __device__ __forceinline__ void coop_pick(P &pp, unsigned long long m_get)
+    {
+        constexpr int RING = sor::ring_rows(NSW);
+        constexpr int par = U & 1;
+        constexpr int e0 = sor::wrapn(U - 1 - 4 * K, RING), e1 = sor::wrapn(U - 3 - 4 * K, RING);
+        constexpr int o0 = sor::wrapn(U - 2 - 4 * K, RING), o1 = sor::wrapn(U - 4 - 4 * K, RING);
+        constexpr int b = (par * NSW + 4 * K) * 32;
+        asm volatile("s_mov_b64 exec, %[m]\n\t"
+                     "ds_read_b32 %[v0], %[a] offset:%[f0]\n\t"
+                     "ds_read_b32 %[v1], %[a] offset:%[f1]\n\t"
+                     "ds_read_b32 %[v2], %[a] offset:%[f2]\n\t"
+                     "ds_read_b32 %[v3], %[a] offset:%[f3]\n\t"
+                     "s_mov_b64 exec, -1"
+                     : [v0] "+v"(pp.E[e0]), [v1] "+v"(pp.E[e1]), [v2] "+v"(pp.O[o0]), [v3] "+v"(pp.O[o1])
+                     : [m] "s"(m_get), [a] "v"(lds_addr(coop_get)), [f0] "n"(b), [f1] "n"(b + 32), [f2] "n"(b + 64), [f3] "n"(b + 96)
+                     : "memory");
+    }
+    template <int NSW, int U, class P>
+    __device__ __forceinline__ void coop_mock(P &pp)
+    {
+        const unsigned long long m_pub = (1ull << 1) | (1ull << 62), m_get = 1ull | (1ull << 63);
+        coop_pair<NSW, U, 0>(pp, m_pub, m_get);
+        if (NSW >= 8) coop_pair<NSW, U, 1>(pp, m_pub, m_get);
+        if (NSW >= 12) coop_pair<NSW, U, 2>(pp, m_pub, m_get);
+        if (NSW >= 16) coop_pair<NSW, U, 3>(pp, m_pub, m_get);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        coop_pick<NSW, U, 0>(pp, m_get);
+        if (NSW >= 8) coop_pick<NSW, U, 1>(pp, m_get);
+        if (NSW >= 12) coop_pick<NSW, U, 2>(pp, m_get);
+        if (NSW >= 16) coop_pick<NSW, U, 3>(pp, m_get);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#else
+    template <int NSW, int U, class P>
+    __device__ __forceinline__ void coop_mock(P &pp)
+    {
+        constexpr int RING = sor::ring_rows(NSW);
+        constexpr int par = U & 1;
+        if (coop_is_pub) {
+#pragma unroll
+            for (int k = 0; k < NSW / 2; ++k) {
+                coop_pub[(par * NSW + k) * 8] = pp.E[sor::wrapn(U - 1 - 2 * k, RING)];
+                coop_pub[(par * NSW + NSW / 2 + k) * 8] = pp.O[sor::wrapn(U - 2 - 2 * k, RING)];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (coop_is_ghost) {
+#pragma unroll
+            for (int k = 0; k < NSW / 2; ++k) {
+                pp.E[sor::wrapn(U - 1 - 2 * k, RING)] = coop_get[(par * NSW + k) * 8];
+                pp.O[sor::wrapn(U - 2 - 2 * k, RING)] = coop_get[(par * NSW + NSW / 2 + k) * 8];
+            }
+        }
+    }
+#endif
+#endif
+
     // ring: [RING slots][2 planes][64 lanes]; slot and plane are compile-time constants at
     // every call site, so each access is one DS instruction with an immediate offset
     __device__ __forceinline__ void ring_store(int slot, int plane, V x) const
@@ -316,9 +417,12 @@ constexpr int min_waves_per_simd(int ns) { return ns == 14 ? 2 : ns >= 12 ? SFL_
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t1,
-                 sor::Tiling t2, SorParams prm)
+                 sor::Tiling t2, SorParams prm, HaloWait hw)
 {
     __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
+#ifdef SFL_PROBE_COOP
+    __shared__ float coop_mem[2 * NS * 8];   // [row parity][value][wave x {left edge, right edge}]
+#endif
 
     // everything derived from the wave index is wave-uniform: tell the compiler (SGPRs)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,6 +455,25 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     const int x0 = sor::strip_x0(t, rect.strip);
     const int r0 = rect.r0, r1 = rect.r1;
 
+    // Halo arrival inside the launch (kernels.h HaloWait): a tile that reads a row a halo message writes -- in either
+    // stream direction it reads at most NS + RING rows beyond its output rows -- waits for the message's epoch; the
+    // other tiles of the launch are already running.  One relaxed poll per turn (all lanes read the one word: one
+    // request), then ONE agent-scope acquire, so that the rows another CU / queue / GPU wrote while this launch was
+    // resident are read from memory, not from this CU's L1.
+    if (hw.flag != nullptr && (r0 - (NS + sor::ring_rows(NS)) < hw.own_lo || r1 + NS + sor::ring_rows(NS) > hw.own_hi)) {  // wave-uniform
+        const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
+        bool arrived = true;
+        while ((int)((unsigned)__hip_atomic_load(hw.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)hw.epoch) < 0) {
+            __builtin_amdgcn_s_sleep(20);
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
+                arrived = false;
+                break;
+            }
+        }
+        if (!arrived && lane == 0) atomicOr(hw.timed_out, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+
     const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
     const unsigned records = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
     // The backend (buffer resources, lane offsets) is built inside each branch: built once in
@@ -371,6 +494,13 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.prio_on = t.rotate;
         bk.start_turns();
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
+#ifdef SFL_PROBE_COOP
+        bk.coop_is_pub = lane == 1 || lane == 62;
+        bk.coop_is_ghost = lane == 0 || lane == 63;
+        bk.coop_pub = coop_mem + wave * 2 + (lane == 62);
+        // lane 0 picks up what the wave on its left published from lane 62, lane 63 what the wave on its right did from lane 1
+        bk.coop_get = coop_mem + ((wave + (lane == 0 ? kWavesPerBlock - 1 : 1)) % kWavesPerBlock) * 2 + (lane == 0);
+#endif
         return bk;
     };
     if (!SFL_PROBE_NO_EDGE && sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
@@ -471,7 +601,7 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                          SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
+                          SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
 {
     auto tiling = [&](int g_begin, int g_end) {
         if (g_end <= g_begin) {
@@ -493,31 +623,33 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     // launch with and without), and a thin slab's launches run next to the halo exchange's kernels, which should
     // not have to compete with raised priorities
     t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE
-                                                : tiles <= resident_waves<B, NS, DX1, ZERO_IN>() && 2 * tiles > 5 * device_simds();
+                            : rows.urgent ? 2
+                                          : tiles <= resident_waves<B, NS, DX1, ZERO_IN>() && 2 * tiles > 5 * device_simds();
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm);
+    const HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0};
+    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm, hw);
     return hipGetLastError();
 }
 
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
 {
     // (a translation unit may hold only the dx == 1 kernels or only the general ones: SFL_DX_PART)
 #if SFL_DX_PART != 1
     if (prm.dx == 1.0f)
-        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
 #endif
 #if SFL_DX_PART != 0
     if (prm.dx != 1.0f)
-        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
 #endif
     return hipErrorInvalidValue;
 }
 
 template <int NS, bool ZERO_IN>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                       SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
+                       SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
@@ -525,19 +657,19 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     if (can2v) {
         // non-temporal stores once the slab's arrays no longer fit the caches (see Lane2)
         if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
-            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
     }
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
 }
 
 template <int NS>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
 }
 
 }  // namespace
@@ -549,11 +681,11 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 #endif
 #define SFL_ENTRY_ARGS                                                                             \
     hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, SorParams prm, \
-        int rows_per_chunk, int sweep
+        int rows_per_chunk, int sweep, const HaloWait *wait
 #define SFL_DEFINE_PART(N, P)                                                                      \
     hipError_t launch_sor_fused_ns##N##_p##P(SFL_ENTRY_ARGS)                                       \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);         \
+        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);   \
     }
 #if SFL_DX_PART == 0
 #define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0)
@@ -589,7 +721,7 @@ SFL_DEFINE_NS(16)
 #if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int sweep)
+                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
 {
     if (rows.g_end <= rows.g_begin && rows.g2_end <= rows.g2_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
@@ -598,8 +730,8 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
     const bool dx1 = prm.dx == 1.0f;
 #define SFL_CASE(N)                                                                                              \
     case N:                                                                                                      \
-        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep)    \
-                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep);
+        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait)    \
+                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }

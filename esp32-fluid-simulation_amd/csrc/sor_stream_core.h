@@ -157,6 +157,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
 
     // the waves that share a SIMD take turns at the top issue priority (Lane2::next_turn; a no-op in the emulator)
     if (U % B::kTurnRows == 0) bk.next_turn();
+#ifdef SFL_PROBE_COOP
+    // TIMING MOCK (diagnostic builds only, wrong results): what sharing column halos between the waves of a block
+    // would add to every row -- see Lane2::coop_mock
+    bk.template coop_mock<NS, U>(pp);
+#endif
 
     // ---- row y enters: hand it to version 0, park its d in the ring, refill the slot ----
     {
@@ -338,7 +343,8 @@ struct Tiling {
     int n_chunks_edge;    // chunks of a boundary strip
     int n_tiles;
     int tile_cols, halo_cols;
-    int rotate;           // the waves of a SIMD take turns at the top issue priority (GPU backend; set by the launcher)
+    int rotate;           // GPU backend, set by the launcher: 1 = the waves of a SIMD take turns at the top issue priority,
+                          // 2 = every wave at the top priority throughout (an urgent launch)
     int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect):
                           // 1 = the odd chunks, 2 = the even ones, 0 = none
 };

@@ -461,6 +461,51 @@ hipError_t launch_spin_us(hipStream_t s, int us)
     return hipGetLastError();
 }
 
+// dst_a <- src_a, dst_b <- src_b (see kernels.h): 16-byte accesses when everything is 16-byte aligned, words otherwise
+template <class W>
+__global__ void __launch_bounds__(kBlock)
+copy_bands_kernel(W *dst_a, const W *src_a, W *dst_b, const W *src_b, size_t words)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < words; k += stride) {
+        if (dst_a) dst_a[k] = src_a[k];
+        if (dst_b) dst_b[k] = src_b[k];
+    }
+}
+
+hipError_t launch_copy_bands(hipStream_t s, void *dst_a, const void *src_a, void *dst_b, const void *src_b, size_t bytes)
+{
+    if (bytes == 0 || (!dst_a && !dst_b)) return hipSuccess;
+    const uintptr_t all = reinterpret_cast<uintptr_t>(dst_a) | reinterpret_cast<uintptr_t>(src_a) |
+                          reinterpret_cast<uintptr_t>(dst_b) | reinterpret_cast<uintptr_t>(src_b) | bytes;
+    if ((all & 15) == 0) {
+        const size_t words = bytes / 16, want = (words + kBlock - 1) / kBlock;
+        copy_bands_kernel<uint4><<<(int)(want < 2048 ? want : 2048), kBlock, 0, s>>>(
+            static_cast<uint4 *>(dst_a), static_cast<const uint4 *>(src_a), static_cast<uint4 *>(dst_b),
+            static_cast<const uint4 *>(src_b), words);
+    } else {   // (every field is made of 4-byte words)
+        const size_t words = bytes / 4, want = (words + kBlock - 1) / kBlock;
+        copy_bands_kernel<uint32_t><<<(int)(want < 2048 ? want : 2048), kBlock, 0, s>>>(
+            static_cast<uint32_t *>(dst_a), static_cast<const uint32_t *>(src_a), static_cast<uint32_t *>(dst_b),
+            static_cast<const uint32_t *>(src_b), words);
+    }
+    return hipGetLastError();
+}
+
+// The word cut-adjacent tiles poll inside a launch (kernels.h HaloWait).  This kernel starts when everything queued
+// before it on its stream -- the halo message, the kernels that relaxed the arrived rows -- has completed and been
+// written back; a relaxed agent-scope store is then all the flag needs.
+__global__ void signal_arrival_kernel(int *flag, int value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value)
+{
+    signal_arrival_kernel<<<1, 64, 0, s>>>(flag, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_apply_forces(hipStream_t s, float *v, Slab g, int g_begin, int g_end,
                                const int *cells_ij, const float *vel_xy, int n)
 {

@@ -110,6 +110,12 @@ extern "C" {
                                      back by this many microseconds on the exchange stream before its copy
                                      starts -- the latency of a real xGMI send / receive that a self-copy does
                                      not have; 0 (default) .. 10000                                   */
+#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, early exchanges: 1 (default) = the launch that needs a halo is queued
+                                     without waiting for the exchange stream; only its tiles next to a cut wait, INSIDE
+                                     the launch, on a device-side count of arrived messages (no cross-stream event on
+                                     the compute stream: the rest of the launch overlaps the tail of the exchange);
+                                     a wait of more than 2 s gives up and is reported by sfl_synchronize.
+                                     0 = the whole launch waits for an event of the exchange stream              */
 
 typedef struct sfl_context sfl_context;
 

@@ -677,11 +677,14 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
     d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
     want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
     infos = []
-    for overlap in (1, 0):
+    # overlapped with the halo's arrival signalled on the device (the default: cut-adjacent tiles wait inside the
+    # launch), overlapped with a cross-stream event in front of the launch, in line
+    for overlap, arrival in ((1, 1), (1, 0), (0, 1)):
         slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
         try:
             sfl.Solver.link_group(slabs)
             slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
+            slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, arrival)
             slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
             slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
             for s in slabs:
@@ -694,8 +697,35 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
         finally:
             for s in slabs:
                 s.close()
-        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}")
-    assert infos[0] == infos[1] and infos[0]["exchanges"] > 0
+        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}, arrival by flag {arrival}")
+    assert infos[0] == infos[1] == infos[2] and infos[0]["exchanges"] > 0
+
+
+def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
+    """SFL_OPT_SOR_ARRIVAL: the launch that needs a halo is queued without a cross-stream event; its cut-adjacent tiles
+    poll a device-side arrival count and acquire.  Many solves back to back on 8 virtual ranks of a grid wide enough
+    that the launches fill the chip (the polling tiles' CUs are busy and L1-warm from the previous launch, the exchange
+    stream's copies and ghost-row launches run beside them), every solve's result against the oracle."""
+    dim_x, dim_y, nranks, iters = 4096, 2048, 8, 31
+    rng = np.random.default_rng(2026)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 10)
+        assert slabs[3].get_option(sfl.capi.OPT_SOR_ARRIVAL) == 1
+        for rep in range(3):
+            d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
+            for s in slabs:
+                s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+            for _ in range(6):       # the same right-hand side again and again: ghost rows keep being rewritten
+                slabs[0].poisson_solve(1.0, iters, OMEGA)
+            slabs[0].synchronize()
+            got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+            assert_bit_equal(got, oracle.poisson_solve(d, 1.0, iters, OMEGA), f"repetition {rep}")
+        assert slabs[3].last_solve_info()["exchanges"] >= 2
+    finally:
+        for s in slabs:
+            s.close()
 
 
 def test_overlapped_exchange_inside_a_full_step(sfl, oracle):
