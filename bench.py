@@ -195,6 +195,49 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+# The sim step's kernels outside the solve (inside sfl_step / sfl_step_n), with SURVEY 8d's algorithmic bytes per cell of
+# what each fuses: K1 + K2 = v in, v out, div out; K5 + K6 = p, v, dye in, v, dye out; the seam = p, v, dye in, dye, v', div out
+STEP_KERNELS = {
+    "advect_divergence_tiled_kernel": {
+        "does": "advect velocity + calculate_divergence (ino:252-256 + ino:274)", "bytes_per_cell": 20,
+        "match": lambda n: "advect_divergence_tiled_kernel" in n},
+    "advect_vec3uq32_tiled_kernel<fuse_grad>": {
+        "does": "subtract_gradient + advect dye (ino:276 + ino:281-287)", "bytes_per_cell": 44,
+        "match": lambda n: "advect_vec3uq32_tiled_kernel" in n and ("<false, true" in n or "ILb0ELb1E" in n)},
+    "seam_tiled_kernel": {
+        "does": "sfl_step_n between two steps: subtract_gradient + advect dye of one, advect velocity + calculate_divergence "
+                "of the next (the projected velocity in between is never stored)", "bytes_per_cell": 48,
+        "match": lambda n: "seam_tiled_kernel" in n},
+}
+
+
+def step_kernel_source_hash():
+    """sha256 (first 16 hex digits) of the sources the step's kernels outside the solve are compiled from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("advect_tiled.hip", "stencil_kernels.hip", "advect_math.h"):
+        with open(os.path.join(ROOT, PKG, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def step_kernel_records(grid):
+    """Per-kernel HBM traffic / duration of the step's kernels from the committed PMC passes (profiles/pmc_traffic.json
+    "step_entries"), only those measured on the kernel sources this run uses."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("step_entries", [])
+    except Exception:
+        return None
+    now, out = step_kernel_source_hash(), {}
+    for e in table:
+        if e["grid"] == list(grid) and e.get("kernel_source_sha16") == now:
+            out[e["kernel"]] = {k: e[k] for k in ("does", "algorithmic_bytes_per_launch", "traffic_bytes_per_launch",
+                                                  "read_bytes_per_launch", "write_bytes_per_launch", "avg_launch_us_rocprof",
+                                                  "frac_of_hbm_peak", "algorithmic_frac_of_hbm_peak", "source",
+                                                  "kernel_source_sha16")}   # later entries win
+    return out or None
+
+
 def pmc_record(grid, fuse, world):
     """Counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json):
     (entry, fresh) for the last entry that matches this exact configuration -- fresh = it was measured on the
@@ -472,7 +515,7 @@ def run_rank(args):
     # A slab reports a back-trace that left its advection halo at synchronize(); every rank still
     # issues the same launches and exchanges, so the failure is recorded, agreed on collectively and
     # never deadlocks a barrier.
-    sim_sps, sim_note = None, None
+    sim_sps, sim_note, sim_sps_calls = None, None, None
     if args.sim_steps > 0:
         failed = []
 
@@ -500,6 +543,15 @@ def run_rank(args):
             sim_note = failed[0] if failed else "a peer rank reported an advection-halo overflow"
         else:
             sim_sps = args.sim_steps / sim_t
+            # A/B on the record: the same steps as ONE sfl_step_n call with the seam kernel switched on (SFL_OPT_STEP_SEAMS,
+            # off by default: it measured slower than the two kernels it fuses, profiles/r04_step_seam.txt)
+            if world == 1 and not emulate:
+                s.set_option(capi.OPT_STEP_SEAMS, 1)
+                t1 = time.perf_counter()
+                s.step_n(args.sim_steps, dtf, 1.0, iters, omega)
+                sync_soft()
+                sim_sps_calls = args.sim_steps / (time.perf_counter() - t1)
+                s.set_option(capi.OPT_STEP_SEAMS, 0)
 
     op_us = None
     if world == 1 and args.sim_steps > 0:
@@ -650,9 +702,15 @@ def run_rank(args):
             "roofline": roofline,
             "sim_steps_per_sec": sim_sps,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None,
-            "sim_step_kernels": ("inside sfl_step advect_velocity + calculate_divergence run as one kernel and "
-                                 "subtract_gradient + advect_color as one (per-kernel times: "
-                                 "profiles/r02_sim_step_kernel_trace.txt); the operators below are timed one by one"),
+            "sim_steps_per_sec_step_n_with_seam_kernel": sim_sps_calls,
+            # the kernels of the step outside the solve: bytes from the committed rocprofv3 PMC passes / their own steady-state
+            # duration there, quoted only while the entries' source hash matches the kernels this run uses
+            "sim_step_kernels": step_kernel_records((size, dim_y)) or
+                                ("no PMC entry matches the current kernel sources (profiles/pmc_traffic.json step_entries, "
+                                 "sha16 " + step_kernel_source_hash() + "): re-run profiles/run_step_pmc.sh"),
+            "sim_step_kernels_note": "inside sfl_step advect_velocity + calculate_divergence run as one kernel and "
+                                     "subtract_gradient + advect_color as one, inside sfl_step_n the seam kernel joins the "
+                                     "second of one step to the first of the next; the operators below are timed one by one",
             "sim_step_per_operator": op_us,
             **({"sim_steps_note": sim_note} if sim_note else {}),
             "device": name,

@@ -20,6 +20,7 @@ OPT_FUSE_DIVERGENCE = 10
 OPT_SMALL_GRID = 11
 OPT_EMULATE_WIRE_US = 12
 OPT_SOR_ARRIVAL = 13
+OPT_STEP_SEAMS = 14
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
@@ -115,6 +116,7 @@ SIGNATURES = {
     "sfl_poisson_solve": (_i, [_ctx, _f, _i, _f]),
     "sfl_subtract_gradient": (_i, [_ctx, _f]),
     "sfl_step": (_i, [_ctx, _f, _f, _i, _f]),
+    "sfl_step_n": (_i, [_ctx, _i, _f, _f, _i, _f]),
     "sfl_queue_forces": (_i, [_ctx, _pi, _pf, _i]),
     "sfl_queue_drags": (_i, [_ctx, C.c_void_p, _i]),
     "sfl_setup_sketch_fields": (_i, [_ctx]),

@@ -70,6 +70,13 @@ hipError_t launch_advect_divergence_tiled(hipStream_t s, float *next_v, float *d
 hipError_t launch_advect_channels(hipStream_t s, void *next_p, const void *p, const float *vel, int dim_x, int dim_y,
                                   float dt, bool no_slip, int channels, int kind);
 
+// The seam between two steps of sfl_step_n on a WHOLE-DOMAIN context: subtract_gradient + dye advection of step k
+// (ino:276, :281-287) and velocity advection + divergence of step k + 1 (ino:252-256, :274) in one pass.  Reads v (the
+// advected, not yet projected velocity of step k), its pressure and the dye; writes the new dye, the advected velocity
+// of step k + 1 and its divergence.  The projected velocity of step k lives in LDS only.  Same bits as the two kernels.
+hipError_t launch_step_seam_tiled(hipStream_t s, uint32_t *next_col, const uint32_t *col, float *next_v, float *div,
+                                  const float *v, const float *pressure, Slab g, float dt, float two_dx_inv);
+
 // ---- finite differences (finitediff.cpp:9-82) ------------------------------------------
 // `kernel` as for the advections: 1 = one thread per cell (stencil_kernels.hip), 2 = the 66 x 34 window of a
 // 64 x 32-cell tile staged in LDS (advect_tiled.hip), 0 = automatic (2 from kAdvectTiledMinCells cells).

@@ -150,7 +150,7 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1, opt_step_seams = 0;
 
     ncclComm_t comm = nullptr;
     bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
@@ -1098,6 +1098,9 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_SOR_ARRIVAL:
             c->opt_sor_arrival = value ? 1 : 0;
             return SFL_OK;
+        case SFL_OPT_STEP_SEAMS:
+            c->opt_step_seams = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -1146,6 +1149,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SMALL_GRID: *value = c->opt_small_grid; return SFL_OK;
         case SFL_OPT_EMULATE_WIRE_US: *value = c->opt_emulate_wire_us; return SFL_OK;
         case SFL_OPT_SOR_ARRIVAL: *value = c->opt_sor_arrival; return SFL_OK;
+        case SFL_OPT_STEP_SEAMS: *value = c->opt_step_seams; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -2059,6 +2063,61 @@ int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
     } else {
         SFL_TRY(sfl_subtract_gradient(ctx, dx));           // ino:276
         SFL_TRY(sfl_advect_color(ctx, dt, 0));             // ino:281-287
+    }
+    return SFL_OK;
+}
+
+// ino:276 + ino:281-287 of one step and ino:252-256 + ino:274 of the next as one kernel (kernels.h launch_step_seam_tiled)
+static int step_seam(sfl_context *c, float dt, float dx)
+{
+    SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
+    SFL_TRY(ensure(c, c->vel_tmp, 8, false));
+    SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+    SFL_TRY(ensure(c, c->col_tmp, 12, false));
+    SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+    SFL_TRY(use_device(c));
+    const float two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36, :78-79
+    HIP_TRY(sfl::launch_step_seam_tiled(c->stream, c->col_tmp, c->col, c->vel_tmp, c->div, c->vel, c->p, c->geom, dt,
+                                        two_dx_inv));
+    std::swap(c->col, c->col_tmp);  // ino:286
+    std::swap(c->vel, c->vel_tmp);  // ino:255 of the next step (the projected velocity of this one was never stored)
+    c->vel_epoch += 2;
+    return SFL_OK;
+}
+
+// The loop of the sim task (ino:249-289) calls the step back to back.  n steps in one call give the library the one
+// fusion a per-step API has no place for: between two steps the projected velocity is written by the last kernel of
+// one and read straight back by the first kernel of the next.  The seam kernel that fuses the two is built, bit-exact
+// and OFF by default (SFL_OPT_STEP_SEAMS): it moves a quarter fewer bytes and still takes 953-976 us at 8192^2 where the
+// two kernels it replaces take 560 + 260 -- a block holds its LDS through three tenants and four barriers, so a CU keeps
+// the memory system less busy than two kernels whose blocks are in different phases (profiles/r04_step_seam.txt).
+int sfl_step_n(sfl_context *ctx, int n, float dt, float dx, int iters, float omega)
+{
+    if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (n < 0) return fail(SFL_ERR_INVALID, "n must be >= 0 (got %d)", n);
+    SFL_TRY(settle_color(ctx));
+    const int64_t cells = (int64_t)ctx->dim_x * ctx->gdim_y;
+    const bool tiled = ctx->opt_advect_kernel == 2 || (ctx->opt_advect_kernel == 0 && cells >= sfl::kAdvectTiledMinCells);
+    const bool seams = n > 1 && ctx->opt_step_seams && ctx->nranks == 1 && !ctx->group && !small_grid(ctx) && tiled &&
+                       ctx->opt_fuse_projection && ctx->opt_fuse_divergence;
+    if (!seams) {
+        for (int k = 0; k < n; ++k) SFL_TRY(sfl_step(ctx, dt, dx, iters, omega));
+        return SFL_OK;
+    }
+    // head of the first step: as sfl_step (queued forces go between its advection and its divergence, ino:264-269)
+    if (can_fuse_divergence(ctx)) {
+        SFL_TRY(advect_velocity_and_divergence(ctx, dt, dx));
+    } else {
+        SFL_TRY(sfl_advect_velocity(ctx, dt, 1));
+        SFL_TRY(apply_queued_forces(ctx));
+        SFL_TRY(sfl_calculate_divergence(ctx, dx));
+    }
+    for (int k = 0; k < n; ++k) {
+        SFL_TRY(sfl_poisson_solve(ctx, dx, iters, omega));                                        // ino:275
+        if (k + 1 < n)
+            SFL_TRY(step_seam(ctx, dt, dx));                                                      // ino:276, :281-287 | :252-256, :274
+        else
+            SFL_TRY(project_and_advect_color(ctx, dt, dx, ctx->opt_advect_halo, false));          // ino:276 + ino:281-287
     }
     return SFL_OK;
 }

@@ -180,6 +180,10 @@ class Solver:
     def step(self, dt, dx=1.0, iters=10, omega=1.96):
         capi.check(self._lib.sfl_step(self._h, dt, dx, iters, omega))
 
+    def step_n(self, n, dt, dx=1.0, iters=10, omega=1.96):
+        """n steps in one call (sfl_step_n): the same results as n x step(), fused across the step boundaries."""
+        capi.check(self._lib.sfl_step_n(self._h, n, dt, dx, iters, omega))
+
     def queue_forces(self, cells_ij, vel_xy):
         cells = np.ascontiguousarray(cells_ij, np.int32).reshape(-1, 2)
         vel = np.ascontiguousarray(vel_xy, np.float32).reshape(-1, 2)

@@ -1,10 +1,14 @@
 #!/bin/bash
-# PMC passes (HBM traffic) over full sim steps at the headline size.  Runs on the GPU box.
+# Kernel trace + PMC passes (HBM traffic) over full sim steps at the headline size -- the kernels of the step outside the
+# solve (bench.py times the steps once as n x sfl_step and once as sfl_step_n, so the two per-step kernels and the seam
+# kernel all appear).  Runs on the GPU box: bash profiles/run_step_pmc.sh [tag]; then, with the summary copied to
+# profiles/, python3 profiles/update_step_table.py gpurun_out/prof_step_<tag> profiles/<summary> <round>
 set -u
-OUT=$PWD/gpurun_out/prof_step_pmc
-mkdir -p $OUT
+OUT=$PWD/gpurun_out/prof_step_${1:-pmc}
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --sim-steps 3"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --sim-steps 6"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_$N -o pmc -- python3 bench.py $ARGS > $OUT/pmc_$N.log 2>&1

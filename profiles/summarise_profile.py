@@ -37,6 +37,9 @@ def short(name):
         label = {"advect_divergence_tiled_kernel": ["no_slip"], "advect_vec2f_tiled_kernel": ["no_slip", "self"],
                  "advect_vec3uq32_tiled_kernel": ["no_slip", "fuse_grad"]}[m.group(1)]
         return m.group(1) + "<" + ", ".join(f"{a}={b}" for a, b in zip(label, flags)) + ">"
+    for key in ("seam_tiled_kernel", "advect_channels_kernel", "copy_bands_kernel", "signal_arrival_kernel"):
+        if key in name:
+            return key
     for key in ("divergence_tiled_kernel", "gradient_tiled_kernel"):
         if key in name:
             return key

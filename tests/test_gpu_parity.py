@@ -1306,3 +1306,85 @@ def test_device_pointer_counts_as_a_write_from_outside(sfl, oracle):
     finally:
         for s in slabs:
             s.close()
+
+
+@pytest.mark.parametrize("dim_x,dim_y,vamp,n", [(256, 192, 60.0, 3), (300, 141, 900.0, 4), (1000, 333, 150.0, 2), (129, 130, 5.0, 5)])
+def test_step_n_fuses_across_step_boundaries_with_the_same_bits(sfl, oracle, dim_x, dim_y, vamp, n):
+    """sfl_step_n (the sim task's loop, ino:249-289): between two steps subtract_gradient + dye advection of one and
+    velocity advection + divergence of the next run as ONE kernel; the projected velocity in between never reaches
+    memory.  Must equal n calls of sfl_step and the oracle's n steps bit for bit -- slow and fast fields (back-traces that
+    leave the LDS windows project their texels on the fly), ragged tile edges, a drag force in the first step."""
+    v, c, _ = random_fields(dim_x, dim_y, dim_x + n, vamp)
+    iters = 7
+    cells = np.array([[dim_x // 3, dim_y // 2], [dim_x - 1, 0]], np.int32)
+    fv = np.array([[35.0, -22.0], [4.0, 9.0]], np.float32)
+    fields = (sfl.capi.FIELD_VELOCITY, sfl.capi.FIELD_DIVERGENCE, sfl.capi.FIELD_PRESSURE, sfl.capi.FIELD_COLOR)
+    got = {}
+    for mode in ("step_n", "separate", "seams_off"):
+        with sfl.Solver(dim_x, dim_y) as s:
+            assert s.get_option(sfl.capi.OPT_STEP_SEAMS) == 0      # an experiment switch: slower than the kernels it fuses
+            if mode == "step_n":
+                s.set_option(sfl.capi.OPT_STEP_SEAMS, 1)
+            s.upload(sfl.capi.FIELD_VELOCITY, v)
+            s.upload(sfl.capi.FIELD_COLOR, c)
+            s.queue_forces(cells, fv)
+            if mode == "separate":
+                for _ in range(n):
+                    s.step(DT, 1.0, iters, OMEGA)
+            else:
+                s.step_n(n, DT, 1.0, iters, OMEGA)
+            s.synchronize()
+            got[mode] = [s.download(f) for f in fields]
+    for name, a, b, cc in zip(("v", "div", "p", "colour"), got["step_n"], got["separate"], got["seams_off"]):
+        assert_bit_equal(a, b, f"step_n vs {n} x step: {name}")
+        assert_bit_equal(a, cc, f"step_n with and without seams: {name}")
+    vo, co = v, c
+    for k in range(n):
+        va = oracle.advect_vec2f(vo, vo, DT, True)
+        if k == 0:
+            for (i, j), u in zip(cells, fv):
+                va[j, i] = u
+        do = oracle.divergence(va, 1.0)
+        po = oracle.poisson_solve(do, 1.0, iters, OMEGA)
+        vo = oracle.subtract_gradient(va, po, 1.0)
+        co = oracle.advect_vec3uq32(co, vo, DT, False)
+    for name, a, b in zip(("v", "div", "p", "colour"), got["step_n"], (vo, do, po, co)):
+        assert_bit_equal(a, b, f"step_n vs oracle: {name}")
+
+
+def test_step_n_where_there_is_nothing_to_fuse(sfl, oracle):
+    """n = 0 / 1, the one-workgroup small-grid path and slab groups: sfl_step_n is n times sfl_step."""
+    v, c, _ = random_fields(61, 81, 9, 40.0)
+    with sfl.Solver(61, 81) as s:
+        s.upload(sfl.capi.FIELD_VELOCITY, v)
+        s.upload(sfl.capi.FIELD_COLOR, c)
+        s.step_n(0, DT, 1.0, 5, OMEGA)
+        s.synchronize()
+        assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), v, "n = 0 leaves the fields alone")
+        s.step_n(3, DT, 1.0, 5, OMEGA)
+        s.synchronize()
+        vo, co = v, c
+        for _ in range(3):
+            vo, do, po, co = oracle.step(vo, co, DT, 1.0, 5, OMEGA)
+        assert_bit_equal(s.download(sfl.capi.FIELD_VELOCITY), vo, "small grid, 3 steps")
+        assert_bit_equal(s.download(sfl.capi.FIELD_COLOR), co, "small grid, 3 steps: dye")
+        with pytest.raises(sfl.SflError):
+            s.step_n(-1, DT, 1.0, 5, OMEGA)
+    dim_x, dim_y, nranks = 192, 256, 2
+    v, c, _ = random_fields(dim_x, dim_y, 10, 40.0)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        slabs[0].step_n(2, DT, 1.0, 6, OMEGA)
+        slabs[0].synchronize()
+        vo, co = v, c
+        for _ in range(2):
+            vo, do, po, co = oracle.step(vo, co, DT, 1.0, 6, OMEGA)
+        assert_bit_equal(np.concatenate([s.download(sfl.capi.FIELD_VELOCITY) for s in slabs], axis=0), vo, "slabs, 2 steps")
+        assert_bit_equal(np.concatenate([s.download(sfl.capi.FIELD_COLOR) for s in slabs], axis=0), co, "slabs, 2 steps: dye")
+    finally:
+        for s in slabs:
+            s.close()
