@@ -542,16 +542,18 @@ def run_rank(args):
         if bad_step:
             sim_note = failed[0] if failed else "a peer rank reported an advection-halo overflow"
         else:
-            sim_sps = args.sim_steps / sim_t
-            # A/B on the record: the same steps as ONE sfl_step_n call with the seam kernel switched on (SFL_OPT_STEP_SEAMS,
-            # off by default: it measured slower than the two kernels it fuses, profiles/r04_step_seam.txt)
-            if world == 1 and not emulate:
-                s.set_option(capi.OPT_STEP_SEAMS, 1)
-                t1 = time.perf_counter()
-                s.step_n(args.sim_steps, dtf, 1.0, iters, omega)
-                sync_soft()
-                sim_sps_calls = args.sim_steps / (time.perf_counter() - t1)
-                s.set_option(capi.OPT_STEP_SEAMS, 0)
+            sim_sps_calls = args.sim_steps / sim_t
+            sim_sps = sim_sps_calls
+            # the sim task's loop calls the step back to back (ino:249-289): the same steps as ONE sfl_step_n call, which on
+            # a whole-domain context joins the last kernel of a step and the first of the next (SFL_OPT_STEP_SEAMS); the same
+            # results (tests/test_gpu_parity.py::test_step_n_*), timed the same way.  Slab ranks run n x sfl_step inside.
+            t1 = time.perf_counter()
+            s.step_n(args.sim_steps, dtf, 1.0, iters, omega)
+            sync_soft()
+            rdzv.barrier()
+            sim_tn, bad_step = rdzv.max([time.perf_counter() - t1, 1.0 if failed else 0.0])
+            if not bad_step:
+                sim_sps = args.sim_steps / sim_tn
 
     op_us = None
     if world == 1 and args.sim_steps > 0:
@@ -702,7 +704,8 @@ def run_rank(args):
             "roofline": roofline,
             "sim_steps_per_sec": sim_sps,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None,
-            "sim_steps_per_sec_step_n_with_seam_kernel": sim_sps_calls,
+            "sim_steps_api": "sfl_step_n(n): one call for the timed steps",
+            "sim_steps_per_sec_as_separate_calls": sim_sps_calls,
             # the kernels of the step outside the solve: bytes from the committed rocprofv3 PMC passes / their own steady-state
             # duration there, quoted only while the entries' source hash matches the kernels this run uses
             "sim_step_kernels": step_kernel_records((size, dim_y)) or

@@ -482,6 +482,7 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
 // never written to memory: 8 B per cell less to write, the 74 x 42 window per tile less to read back.  Same arithmetic
 // in the same order as the two kernels above (a back-trace that leaves a window projects the texels it needs on the fly
 // from memory: the same expressions, so the same bits); whole-domain contexts.
+constexpr int kPX = kDX + 2, kPY = kDY + 2;   // pressure window
 
 // finitediff.cpp:41-73 for one cell: v - grad p, a missing neighbour's pressure is the cell's own
 template <class P>
@@ -536,14 +537,11 @@ __device__ __forceinline__ float2 sample_global_projected(const float2 *v, const
     return r;
 }
 
-#ifndef SFL_SEAM_THREADS
-#define SFL_SEAM_THREADS 512
-#endif
-#ifndef SFL_SEAM_WAVES
-#define SFL_SEAM_WAVES 6   // waves per SIMD the register allocator must leave room for (6 = three blocks of 512 threads per CU)
-#endif
+// 512 threads; the register allocator leaves room for 6 waves per SIMD = three blocks per CU (80 VGPRs; two blocks at the 86 it
+// would take by itself: 836 against 780 us; four blocks at 64 VGPRs spill: 1390 us)
+constexpr int kThreadsSeam = 512;
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, SFL_SEAM_WAVES)
+__global__ void __launch_bounds__(THREADS, 6)
 seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *__restrict__ next_v,
                   float *__restrict__ div, const float2 *v, const float *pressure, Slab g, TileGrid tg, float dt,
                   float two_dx_inv)
@@ -553,21 +551,33 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
     constexpr int kLoadsV = (kDX * kDY + THREADS - 1) / THREADS;
     constexpr int kLoadsC = (kPlane + THREADS - 1) / THREADS;
     static_assert(kRing <= THREADS, "one ring cell per thread");
-    static_assert(kDX * kDY * 2 <= 3 * kPlane && kVX * kVY * 2 <= 3 * kPlane, "one LDS buffer, three tenants in turn");
-    // ONE buffer of the dye window's size (34.5 KB: four blocks per CU, as the dye kernel), used in turn by the projected
-    // velocity window of step k, the dye window, and the advected velocities of step k + 1; what has to survive a change
-    // of tenant waits in registers (the dye texels while the velocity is advected, the advected cells while the dye is).
-    __shared__ uint32_t lds[3 * kPlane];
-    float2 *lds_v = reinterpret_cast<float2 *>(lds);
+    constexpr int kLoadsP = (kPX * kPY + THREADS - 1) / THREADS;
+    constexpr int kWords = kPX * kPY + 2 * kDX * kDY;   // pressure window + velocity window, in 4-byte words
+    static_assert(3 * kPlane <= kWords && kVX * kVY * 2 <= kWords, "one LDS buffer, tenants in turn");
+    // ONE buffer (38.2 KB: four blocks per CU), used in turn by the pressure window + the projected velocity window of step
+    // k, the dye window, and the advected velocities of step k + 1; what has to survive a change of tenant waits in
+    // registers (the dye texels while the velocity is projected and advected, the advected cells while the dye is).
+    __shared__ uint32_t lds[kWords];
+    float *lds_p = reinterpret_cast<float *>(lds);
+    float2 *lds_v = reinterpret_cast<float2 *>(lds + kPX * kPY);
+    static_assert((kPX * kPY) % 2 == 0, "the velocity window starts 8-byte aligned");
     int tx, ty;
     if (!tile_of_block(tg, tx, ty)) return;
     const int x0 = tx * kTX, y0 = ty * kTY;
     const int i_max = g.dim_x - 1, j_max = g.gdim_y - 1;
     const Window wv = window_of<kRD>(x0, y0, g, 0, g.gdim_y);
     const Window wc = window_of<kR>(x0, y0, g, 0, g.gdim_y);
+    const int px0 = x0 - kRD - 1, py0 = y0 - kRD - 1;   // the pressure window is one cell wider than the velocity window
     uq3 got_c[kLoadsC];
     {   // every load of the block in flight before the first LDS write
         float2 got_v[kLoadsV];
+        float got_p[kLoadsP];
+#pragma unroll
+        for (int k = 0; k < kLoadsP; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            const int r = e / kPX, gi = px0 + (e - r * kPX), gj = py0 + r;
+            got_p[k] = (r < kPY && gi >= 0 && gi <= i_max && gj >= 0 && gj <= j_max) ? pressure[lcell(g, gi, gj)] : 0.0f;
+        }
 #pragma unroll
         for (int k = 0; k < kLoadsV; ++k) {
             const int e = threadIdx.x + k * THREADS;
@@ -578,8 +588,14 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
             const int e = threadIdx.x + k * THREADS;
             got_c[k] = window_has<kSX>(wc, e) ? load_uq3(col, window_cell<kSX>(wc, g, e)) : uq3{0u, 0u, 0u};
         }
-        // ino:276 on the velocity window: every thread projects the cells it loaded (five pressure loads per cell from
-        // memory, as the fused projection of the dye kernel does)
+#pragma unroll
+        for (int k = 0; k < kLoadsP; ++k) {
+            const int e = threadIdx.x + k * THREADS;
+            if (e < kPX * kPY) lds_p[e] = got_p[k];
+        }
+        __syncthreads();
+        // ino:276 on the velocity window: every thread projects the cells it loaded, pressure from LDS (five scattered loads
+        // per window cell from memory cost 300 of the kernel's 970 us: tools/r04/run13.sh)
 #pragma unroll
         for (int k = 0; k < kLoadsV; ++k) {
             const int e = threadIdx.x + k * THREADS;
@@ -587,7 +603,8 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
             float2 u = got_v[k];
             if (window_has<kDX>(wv, e)) {
                 const int r = e / kDX, gi = wv.sx0 + (e - r * kDX), gj = wv.sy0 + r;
-                u = project_cell(u, gi, gj, i_max, j_max, two_dx_inv, [&](int a, int b) { return pressure[lcell(g, a, b)]; });
+                u = project_cell(u, gi, gj, i_max, j_max, two_dx_inv,
+                                 [&](int a, int b) { return lds_p[(b - py0) * kPX + (a - px0)]; });
             }
             lds_v[e] = u;
         }
@@ -786,7 +803,7 @@ hipError_t launch_step_seam_tiled(hipStream_t s, uint32_t *next_col, const uint3
                                   const float *v, const float *pressure, Slab g, float dt, float two_dx_inv)
 {
     const TileGrid tg = tile_grid(g.dim_x, g.gdim_y);
-    seam_tiled_kernel<SFL_SEAM_THREADS><<<dim3(tg.per_xcd * kXcds), dim3(SFL_SEAM_THREADS), 0, s>>>(
+    seam_tiled_kernel<kThreadsSeam><<<dim3(tg.per_xcd * kXcds), dim3(kThreadsSeam), 0, s>>>(
         next_col, col, reinterpret_cast<float2 *>(next_v), div, reinterpret_cast<const float2 *>(v), pressure, g, tg, dt,
         two_dx_inv);
     return hipGetLastError();

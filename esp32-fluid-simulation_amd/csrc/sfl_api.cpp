@@ -150,7 +150,7 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1, opt_step_seams = 0;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1, opt_step_seams = 1;
 
     ncclComm_t comm = nullptr;
     bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
@@ -2087,10 +2087,8 @@ static int step_seam(sfl_context *c, float dt, float dx)
 
 // The loop of the sim task (ino:249-289) calls the step back to back.  n steps in one call give the library the one
 // fusion a per-step API has no place for: between two steps the projected velocity is written by the last kernel of
-// one and read straight back by the first kernel of the next.  The seam kernel that fuses the two is built, bit-exact
-// and OFF by default (SFL_OPT_STEP_SEAMS): it moves a quarter fewer bytes and still takes 953-976 us at 8192^2 where the
-// two kernels it replaces take 560 + 260 -- a block holds its LDS through three tenants and four barriers, so a CU keeps
-// the memory system less busy than two kernels whose blocks are in different phases (profiles/r04_step_seam.txt).
+// one and read straight back by the first kernel of the next -- the seam kernel does both and never stores it
+// (780 us at 8192^2 where the two kernels take 568 + 254; SFL_OPT_STEP_SEAMS, profiles/r04_step_seam.txt).
 int sfl_step_n(sfl_context *ctx, int n, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");

@@ -116,12 +116,10 @@ extern "C" {
                                      the compute stream: the rest of the launch overlaps the tail of the exchange);
                                      a wait of more than 2 s gives up and is reported by sfl_synchronize.
                                      0 = the whole launch waits for an event of the exchange stream              */
-#define SFL_OPT_STEP_SEAMS 14      /* sfl_step_n on a whole-domain context with the tile kernels: 1 = between two steps
+#define SFL_OPT_STEP_SEAMS 14      /* sfl_step_n on a whole-domain context with the tile kernels: 1 (default) = between two steps
                                      subtract_gradient + dye advection of one and velocity advection + divergence of the
                                      next run as ONE kernel (the projected velocity in between is never written to memory);
-                                     0 (default) = n times sfl_step.  Same results either way; the seam kernel moves fewer
-                                     bytes but measured slower than the two kernels it replaces (round 4: 953-976 us
-                                     against 560 + 260 at 8192^2), so it is an experiment switch, not the default   */
+                                     0 = n times sfl_step.  Same results either way                              */
 
 typedef struct sfl_context sfl_context;
 
@@ -320,7 +318,7 @@ SFL_API int sfl_advect_external(sfl_context *ctx, void *next_p_dev, const void *
 SFL_API int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega);
 /* n sim steps, exactly as n calls of sfl_step (the sim task's loop, ino:249-289, calls the step back to back); forces
  * queued before the call go into the FIRST step.  Knowing the next step lets the library fuse across the step boundary
- * (SFL_OPT_STEP_SEAMS, off by default).  n == 0 does nothing.                                                       */
+ * (SFL_OPT_STEP_SEAMS).  n == 0 does nothing.                                                                       */
 SFL_API int sfl_step_n(sfl_context *ctx, int n, float dt, float dx, int iters, float omega);
 /* Queue point forces applied by the next sfl_step between the velocity advection and the
  * divergence (ino:264-269): velocity[index(cells[2k], cells[2k+1])] = (vel[2k], vel[2k+1])

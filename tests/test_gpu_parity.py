@@ -1322,9 +1322,9 @@ def test_step_n_fuses_across_step_boundaries_with_the_same_bits(sfl, oracle, dim
     got = {}
     for mode in ("step_n", "separate", "seams_off"):
         with sfl.Solver(dim_x, dim_y) as s:
-            assert s.get_option(sfl.capi.OPT_STEP_SEAMS) == 0      # an experiment switch: slower than the kernels it fuses
-            if mode == "step_n":
-                s.set_option(sfl.capi.OPT_STEP_SEAMS, 1)
+            assert s.get_option(sfl.capi.OPT_STEP_SEAMS) == 1
+            if mode == "seams_off":
+                s.set_option(sfl.capi.OPT_STEP_SEAMS, 0)
             s.upload(sfl.capi.FIELD_VELOCITY, v)
             s.upload(sfl.capi.FIELD_COLOR, c)
             s.queue_forces(cells, fv)

@@ -2,7 +2,7 @@
 # seam kernel variants: per-kernel durations from a kernel trace
 set -u
 export TMPDIR=/tmp
-for v in product seam_t256w4 seam_t512w4 seam_t256w3; do
+for v in product seam_late6 seam_late8 seam_late4; do
   O=$PWD/gpurun_out/r04/trace_seam_$v
   rm -rf $O; mkdir -p $O
   if [ $v = product ]; then prog="bench.py"; else prog="tools/with_lib.py build/variants/$v/libsfl_hip.so bench.py"; fi
