@@ -266,7 +266,7 @@ def parse_args(argv=None):
     ap.add_argument("--sor-rows", type=int, default=0)
     ap.add_argument("--sor-halo", type=int, default=0, help="rows of p exchanged per superstep (0 = auto)")
     ap.add_argument("--lane-cells", type=int, default=0, help="cells per lane of the fused kernel (0 auto, 2)")
-    ap.add_argument("--sim-steps", type=int, default=3, help="full sim steps timed after the main region")
+    ap.add_argument("--sim-steps", type=int, default=8, help="full sim steps timed after the main region")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the reference CPU solve (and with it the parity check)")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the reference solve on rank 0")
