@@ -287,8 +287,8 @@ def parse_args(argv=None):
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
     ap.add_argument("--arrival-by-event", action="store_true",
-                    help="SFL_OPT_SOR_ARRIVAL = 0: the launch behind a halo waits for a cross-stream event instead of "
-                         "letting its cut-adjacent tiles poll the device-side arrival count (A/B)")
+                    help="SFL_OPT_SOR_ARRIVAL = 0: early halo exchanges behind cross-stream events (round 3's scheme) instead of "
+                         "in-time exchanges counted on the device (A/B)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
     ap.add_argument("--dry-run", action="store_true",

@@ -116,9 +116,6 @@ hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g
 struct SorRows {
     int g_begin, g_end;
     int g2_begin, g2_end;
-    int urgent;   // 1: every wave of the launch runs at the top issue priority -- a small launch on the exchange
-                  // stream that the compute stream's resident launch is waiting for (the ghost rows behind a halo
-                  // message) must not queue up behind that launch's waves on the SIMDs they share
 };
 // Device-side halo arrival.  A launch may start BEFORE a halo message it depends on has arrived: its tiles whose
 // input rows all lie inside [own_lo, own_hi) -- rows no message writes -- run at once, the others (the tiles next
@@ -126,18 +123,30 @@ struct SorRows {
 // counts up, launch_signal_arrival), then make the arrived rows visible to their CU (agent-scope acquire).  A wait
 // that lasts longer than kHaloWaitTimeoutUs gives up and raises *timed_out (results are then wrong: the host turns
 // the word into an error): a lost message must never hang the GPU.  flag == nullptr: nobody waits.
+//
+// The other direction, in the same struct: `done` != nullptr makes the tiles whose output rows reach below send_lo_end or
+// above send_hi_begin -- the rows the NEXT halo message carries -- SENDERS: they run at the top issue priority, and when
+// their stores have been written back (agent-scope release) each adds one to *done.  The exchange stream waits for the
+// count (launch_wait_count) instead of an event behind the whole launch: the message leaves while the rest of the launch
+// is still running, and the compute stream carries no event at all.
 struct HaloWait {
     const int *flag;
     int *timed_out;
     int epoch;
     int own_lo, own_hi;
+    int *done;
+    int send_lo_end, send_hi_begin;
 };
 constexpr int kHaloWaitTimeoutUs = 2000000;
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait = nullptr);
+                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait = nullptr,
+                            int *senders = nullptr);   // *senders = tiles of this launch that will add to *wait->done
 // *flag = value, visible to every CU (stream-ordered behind the message / the kernels that relaxed it)
 hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value);
+// One wave that returns when *count has reached `target` (signed distance; sender tiles of launches on ANOTHER stream
+// count it up) or after kHaloWaitTimeoutUs, raising *timed_out: what follows on the stream starts then.
+hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out);
 
 // ---- small grids: one workgroup, fields in LDS (small_grid.hip) -------------------------------------
 // WHOLE-DOMAIN arrays of dim_x * dim_y <= kSmallGridMaxCells cells (16 B of LDS per cell: 96 KB of the CU's 160;

@@ -103,6 +103,8 @@ struct sfl_context {
     int *d_arrival = nullptr;      // [1] halo messages arrived (and relaxed) so far: what cut-adjacent tiles poll inside a
                                    //     launch (kernels.h HaloWait); [2] such a wait timed out
     int arrival_epoch = 0;         // the last value queued for [1]
+    int *d_done = nullptr;         // [3] sender tiles finished so far (kernels.h HaloWait::done): what the exchange stream waits
+    int done_target = 0;           //     for before a halo message leaves; done_target = the count the launches queued so far reach
 
     // queued point forces (ino:264-269)
     std::vector<int> force_cells;
@@ -387,14 +389,23 @@ int effective_halo(const sfl_context *c, int fuse)
     return h < fuse ? fuse : h;
 }
 
+// Exchanges IN TIME with everything counted on the device (run_poisson_in_time; SFL_OPT_SOR_ARRIVAL) instead of early exchanges
+// behind cross-stream events: slabs with a transport, the fused kernel, exchanges overlapped.
+bool in_time_exchanges(const sfl_context *c)
+{
+    return c->opt_sor_arrival && c->opt_sor_overlap && c->nranks > 1 && c->opt_sor_kernel != 1 &&
+           (c->comm || c->group || c->emulated);
+}
+
 // ---- poisson_solve executor --------------------------------------------------------------
 // One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
 // all pieces read c->p and write c->p_alt; the caller swaps once per step).
 // `in` / `out` = the step's input and output arrays (null: c->p / c->p_alt); `on` = stream (null: the compute stream)
 int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
                     int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const float *in = nullptr,
-                    float *out = nullptr, const sfl::HaloWait *wait = nullptr, int urgent = 0)
+                    float *out = nullptr, const sfl::HaloWait *wait = nullptr, int *senders = nullptr)
 {
+    if (senders) *senders = 0;
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
     if (!in) in = c->p;
     if (!out) out = c->p_alt;
@@ -405,12 +416,12 @@ int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParam
     // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
     const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
     HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, out, st.from_zero ? nullptr : in, c->div, c->geom,
-                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end, urgent}, st.nsweeps, st.first_colour,
-                                  prm, c->opt_sor_rows, sweep, wait));
+                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
+                                  prm, c->opt_sor_rows, sweep, wait, senders));
     return SFL_OK;
 }
 
-// Device-side halo arrival (SFL_OPT_SOR_ARRIVAL, kernels.h HaloWait).  The exchange stream counts a context's arrived
+// Device-side halo arrival (run_poisson_in_time, kernels.h HaloWait).  The exchange stream counts a context's arrived
 // messages in a device word; the next launch on the compute stream is queued WITHOUT a cross-stream event and lets only
 // its cut-adjacent tiles wait for the count.
 int signal_arrival(const std::vector<sfl_context *> &peers, hipStream_t xstream)
@@ -431,6 +442,8 @@ sfl::HaloWait arrival_wait(const sfl_context *c)
     w.epoch = c->arrival_epoch;
     w.own_lo = c->rank > 0 ? c->g0 : -(1 << 30);                 // no cut on that side: nothing to wait for
     w.own_hi = c->rank < c->nranks - 1 ? c->g1 : (1 << 30);
+    w.done = nullptr;
+    w.send_lo_end = w.send_hi_begin = 0;
     return w;
 }
 
@@ -521,6 +534,61 @@ int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, i
     return await_exchange(peers, o);
 }
 
+// Exchanges IN TIME (slab_plan.cpp kernel 3; SFL_OPT_SOR_ARRIVAL): the halo of a superstep is sent after the launch that
+// produces it, as in the textbook -- but nothing waits for a whole launch any more.  The launch in front of an exchange
+// marks the tiles whose rows the message carries as SENDERS (top priority; each counts itself once its rows are written
+// back); the exchange stream waits for that count, not for the launch, so the message leaves while the rest of the launch
+// is still running; the launch behind the exchange is queued at once and only its cut-adjacent tiles wait for the arrival
+// count.  No event on the compute stream, no ghost launch, no launch split.  (The right-hand side at the head of a solve
+// was produced by other kernels: its exchange still starts behind an event.)
+int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                        const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
+{
+    bool flagged = false;   // the next launch's cut-adjacent tiles wait for the arrival count
+    const size_t n = progs[0].size();
+    for (size_t i = 0; i < n; ++i) {
+        const sfl_plan_step &st0 = progs[0][i];
+        if (st0.kind == SFL_STEP_EXCHANGE) {   // the right-hand side (a p exchange is taken together with the launch before it)
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false));
+            SFL_TRY(signal_arrival(peers, o.xstream));
+            flagged = true;
+            continue;
+        }
+        const bool sends = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE && progs[0][i + 1].field == SFL_FIELD_PRESSURE;
+        for (size_t k = 0; k < peers.size(); ++k) {
+            sfl_context *c = peers[k];
+            const sfl_plan_step &st = progs[k][i];
+            sfl::HaloWait w = arrival_wait(c);
+            if (!flagged) w.flag = nullptr;
+            if (sends) {
+                const sfl_plan_step &x = progs[k][i + 1];
+                w.done = c->d_done;
+                w.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                w.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+            }
+            int senders = 0;
+            SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr, nullptr, nullptr,
+                                    (flagged || sends) ? &w : nullptr, &senders));
+            c->done_target += senders;
+            std::swap(c->p, c->p_alt);
+            ++c->last_launches;
+        }
+        flagged = false;
+        if (sends) {
+            const sfl_plan_step &x = progs[0][i + 1];
+            for (sfl_context *c : peers) {
+                SFL_TRY(use_device(c));
+                HIP_TRY(sfl::launch_wait_count(o.xstream, c->d_done, c->done_target, c->d_arrival + 1));
+            }
+            SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin));
+            SFL_TRY(signal_arrival(peers, o.xstream));
+            flagged = true;
+            ++i;   // the exchange step has been issued
+        }
+    }
+    return SFL_OK;
+}
+
 // The fused kernel's program on slabs, with the halo exchanges OVERLAPPED (cut-adjacent
 // rows first, exchange on a second stream).  The plan is unchanged (slab_plan.cpp); what changes
 // is the order in which the rows of two launches are issued around an exchange of H rows:
@@ -548,7 +616,8 @@ int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &p
 {
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
-    const int rc = run_poisson_overlapped_steps(ctx, peers, progs, prm, o);
+    const int rc = in_time_exchanges(ctx) ? run_poisson_in_time(ctx, peers, progs, prm, o)
+                                          : run_poisson_overlapped_steps(ctx, peers, progs, prm, o);
     if (rc != SFL_OK) {
         // a launch or an RCCL call failed half way: nothing of this solve may still be in flight on the exchange
         // stream when the caller looks at (or destroys) the context; the error message of the failure is kept
@@ -566,12 +635,6 @@ int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context
 {
     bool pending = false;  // an exchange is in flight that the next launch's cut-adjacent rows need
     bool behind_early = false;  // ... an early one, with a launch queued behind it: the next launch needs all of it
-    // Device-side arrival (early-exchange plans): no event between the exchange stream and the launch that needs the
-    // halo -- that launch is queued at once and its cut-adjacent tiles poll the arrival count (`flagged` = the next
-    // launch on the compute stream carries the wait).  Every p exchange of such a plan is an early one; the classic
-    // branches below then only ever see the exchange of the right-hand side.
-    const bool by_flag = ctx->opt_sor_arrival && effective_halo(ctx, effective_fuse(ctx)) >= 2 * effective_fuse(ctx);
-    bool flagged = false;
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -582,7 +645,9 @@ int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context
             // wire.  Exchange stream: the message (rows beyond that depth), then the same launch's passes on the
             // ghost rows it feeds (output rows [g_begin, g0) and [g1, g_end)).  Both read p and write p_alt, on
             // disjoint rows; the message lands in rows of p that the owned-row launch reads only into its
-            // throw-away rim.  The launch AFTER this one waits for `arrived`.
+            // throw-away rim.  The launch AFTER this one waits for `arrived` -- WHOLE: it overwrites the owned rows this
+            // rank's own outgoing message is still being read from (round 4 let only its cut-adjacent tiles wait, on a
+            // device-side count: one solve in 26 000 came out wrong, profiles/r04_exchanges_counted_on_the_device.txt).
             if (pending) SFL_TRY(await_exchange(peers, o));
             pending = behind_early = false;
             SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, st0.rows, st0.g_begin, false));
@@ -591,47 +656,16 @@ int run_poisson_overlapped_steps(sfl_context *ctx, const std::vector<sfl_context
                 const sfl_plan_step &st = progs[k][i + 1];
                 const int lo = c->rank > 0 ? c->g0 : st.g_begin;
                 const int hi = c->rank < c->nranks - 1 ? c->g1 : st.g_end;
-                // (a launch that is itself the first after an earlier exchange -- a halo of exactly two launches --
-                // reads that exchange's ghost rows: its cut-adjacent tiles wait for them)
-                const sfl::HaloWait w = arrival_wait(c);
-                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi, 0, 0, nullptr, nullptr, nullptr, flagged ? &w : nullptr));  // compute stream
-                // behind the message, on the exchange stream -- urgent when the compute stream's next launch will be
-                // resident and waiting for it: its waves share the SIMDs with that launch's
-                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream, nullptr, nullptr, nullptr, by_flag));
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));                                      // compute stream
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream));     // behind the message
             }
-            flagged = false;
-            if (by_flag) {
-                SFL_TRY(signal_arrival(peers, o.xstream));
-                flagged = true;
-            } else {
-                SFL_TRY(mark_arrived(peers, o));
-                pending = behind_early = true;
-            }
+            SFL_TRY(mark_arrived(peers, o));
             for (sfl_context *c : peers) {
                 std::swap(c->p, c->p_alt);
                 ++c->last_launches;
             }
+            pending = behind_early = true;
             ++i;  // the launch has been issued
-            continue;
-        }
-        if (by_flag && st0.kind == SFL_STEP_EXCHANGE && !pending) {
-            // (the right-hand side at the head of a solve) the message, then the arrival count; the launch that
-            // follows is issued whole, its cut-adjacent tiles wait inside it
-            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false));
-            SFL_TRY(signal_arrival(peers, o.xstream));
-            flagged = true;
-            continue;
-        }
-        if (flagged && st0.kind == SFL_STEP_SOR) {
-            for (size_t k = 0; k < peers.size(); ++k) {
-                sfl_context *c = peers[k];
-                const sfl_plan_step &st = progs[k][i];
-                const sfl::HaloWait w = arrival_wait(c);
-                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr, nullptr, nullptr, &w));
-                std::swap(c->p, c->p_alt);
-                ++c->last_launches;
-            }
-            flagged = false;
             continue;
         }
         if (st0.kind == SFL_STEP_EXCHANGE) {  // (classic p exchanges are started by the launch before them)
@@ -714,8 +748,9 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
-        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel,
-                                          effective_halo(ctx, fuse), ctx->solve_tail));
+        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse,
+                                          kernel == 2 && in_time_exchanges(ctx) ? 3 : kernel, effective_halo(ctx, fuse),
+                                          ctx->solve_tail));
         c->last_launches = c->last_exchanges = 0;
         c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
@@ -936,7 +971,7 @@ int sfl_plan_poisson_tail(int dim_y, int nranks, int rank, int iters, int fuse, 
                           sfl_plan_step *steps, int cap, int *n_steps)
 {
     if (dim_y < 2 || nranks < 1 || rank < 0 || rank >= nranks || iters < 0 || !n_steps || halo < 0 || tail < 0 ||
-        (kernel != 1 && kernel != 2) || (kernel == 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
+        (kernel < 1 || kernel > 3) || (kernel >= 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
         return fail(SFL_ERR_INVALID, "bad plan query");
     const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo, tail);
     *n_steps = (int)v.size();
@@ -949,7 +984,7 @@ int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int k
                      sfl_plan_step *steps, int cap, int *n_steps)
 {
     if (dim_y < 2 || nranks < 1 || rank < 0 || rank >= nranks || iters < 0 || !n_steps ||
-        (kernel != 1 && kernel != 2) || (kernel == 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
+        (kernel < 1 || kernel > 3) || (kernel >= 2 && (fuse < 2 || (fuse & 1) || fuse > SFL_MAX_FUSE)))
         return fail(SFL_ERR_INVALID, "bad plan query");
     if (halo < 0) return fail(SFL_ERR_INVALID, "bad plan query");
     const std::vector<sfl_plan_step> v = sfl::plan_poisson(dim_y, nranks, rank, iters, fuse, kernel, halo);
@@ -1001,6 +1036,7 @@ int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int ran
     HIP_TRY(hipMemset(flag, 0, 4 * sizeof(int)));
     c->halo_flag = static_cast<int *>(flag);
     c->d_arrival = c->halo_flag + 1;
+    c->d_done = c->halo_flag + 3;
     *out = c.release();
     return SFL_OK;
 }

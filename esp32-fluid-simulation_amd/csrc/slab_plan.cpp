@@ -63,8 +63,12 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
     const std::vector<int> passes = sor_pass_plan(iters, fuse);
     if (halo < fuse) halo = fuse;
 
-    if (tail < 0 || !(multi && halo >= 2 * fuse + tail)) tail = 0;  // (only the early-exchange plan carries a tail)
-    if (multi && halo >= 2 * fuse) {
+    // kernel 3 = kernel 2's launches with IN-TIME exchanges at every halo depth: the halo of a superstep is sent after the
+    // launch that produces it (the executor lets it leave as soon as that launch's cut-adjacent tiles are done and lets
+    // only the next launch's cut-adjacent tiles wait for it: sfl_api.cpp run_poisson_in_time)
+    const bool in_time = kernel == 3;
+    if (tail < 0 || !multi || (!in_time && halo < 2 * fuse + tail) || (in_time && halo < fuse + tail)) tail = 0;
+    if (multi && halo >= 2 * fuse && !in_time) {
         // EARLY exchanges (halo of at least two launches).  A launch needs `nsweeps` valid ghost rows to produce
         // its own rows; everything deeper only feeds later launches.  So the halo for the next group of launches
         // is sent ONE LAUNCH EARLY -- before the last launch e of the running group, while the ghost rows are
@@ -119,12 +123,14 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
         }
         return prog;
     }
+    // (a tail -- in-time plans only get here with one -- is carried by every superstep: `tail` ghost rows stay exact behind
+    // each launch, so the last launch of the solve leaves them as well; a superstep then holds halo - tail passes)
     std::vector<std::vector<int>> groups;
     for (int n : passes) {
         int sum = 0;
         if (!groups.empty())
             for (int m : groups.back()) sum += m;
-        if (groups.empty() || !multi || sum + n > halo) groups.emplace_back();
+        if (groups.empty() || !multi || sum + n > halo - tail) groups.emplace_back();
         groups.back().push_back(n);
     }
     if (multi) {
@@ -136,16 +142,17 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
         }
         // pass j of a launch relaxes its output rows +- (n - j): the right-hand side is needed
         // one row less than p, once per solve
-        if (deepest > 1) prog.push_back(exchange(SFL_FIELD_DIVERGENCE, deepest - 1));
+        if (deepest + tail > 1) prog.push_back(exchange(SFL_FIELD_DIVERGENCE, deepest + tail - 1));
     }
     bool first = true;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         int left = 0;
         for (int m : groups[gi]) left += m;
-        if (multi && gi > 0) prog.push_back(exchange(SFL_FIELD_PRESSURE, left));
+        // (the `tail` ghost rows next to the cut are still exact: the last launch of the superstep before left them)
+        if (multi && gi > 0) prog.push_back(exchange(SFL_FIELD_PRESSURE, left, tail));
         for (int n : groups[gi]) {
             left -= n;
-            const int extra = multi ? left : 0;
+            const int extra = multi ? left + tail : 0;
             sfl_plan_step c{};
             c.kind = SFL_STEP_SOR;
             c.g_begin = g0 - extra < 0 ? 0 : g0 - extra;

@@ -135,7 +135,7 @@ struct WaveCommon {
     // 228 -> 217 us; profiles/r03_priority_rotation.txt).
     __device__ __forceinline__ void start_turns()
     {
-        if (prio_on == 2) {   // an urgent launch (SorRows::urgent): top priority from the first instruction, no turns
+        if (prio_on == 2) {   // a sender tile (HaloWait::done): top priority from the first instruction, no turns
             __builtin_amdgcn_s_setprio(3);
             return;
         }
@@ -187,13 +187,19 @@ struct WaveCommon {
 // write stream from displacing the halo rows neighbouring tiles are about to re-read (8192^2:
 // -1.1 %, 8192 x 4096: -2.3 .. -5 %); on cache-resident slabs the next launch WANTS those rows in
 // cache (8192 x 1024: +9 %), so the launcher sets it from the slab size.
-template <int NS, bool VEC, bool ZERO_IN, bool NT = false>
+// ST = cache policy of the p stores (VEC only): 0 plain; 2 non-temporal (NT, above); 16 = sc1, WRITTEN THROUGH to memory -- the launch
+// in front of an in-time halo exchange, whose sender tiles publish their rows to a copy / send kernel on another stream (or GPU)
+// while the launch is still running: with plain stores every sender would have to write back its XCD's whole L2 first
+// (buffer_wbl2: the launch took 48 instead of 24 us), written-through rows only have to be waited for (8192 x 1024: +0.5 %
+// for the launch, profiles/r04_experiments_without_gain.txt 3).
+template <int NS, bool VEC, bool ZERO_IN, int ST = 0>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
         // three rows in flight ahead of the pipeline: six cost 12 more VGPRs (and, with the rhs read-ahead, spills
     // at NS = 16) without being faster (profiles/r02_rhs_read_ahead.txt)
     static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 3, kTurnRows = SFL_PRIO_ROWS;
+    static constexpr int kStoreAux = VEC ? ST : 0;
     // LDS per wave: the rhs ring (RING rows x 2 planes x 64 lanes x 4 B)
     static constexpr int kRingFloats = sor::ring_rows(NS) * 2 * 64;
 
@@ -278,7 +284,7 @@ struct Lane2 : WaveCommon {
                 v2f o;
                 o.x = a;
                 o.y = b;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, SFL_PROBE_P_STORE_AUX ? SFL_PROBE_P_STORE_AUX : NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, o), rs_out, off_out, soff, SFL_PROBE_P_STORE_AUX ? SFL_PROBE_P_STORE_AUX : ST);
             }
         } else {
             if (a_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a), rs_out, off_out, soff, 0);
@@ -460,7 +466,14 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // other tiles of the launch are already running.  One relaxed poll per turn (all lanes read the one word: one
     // request), then ONE agent-scope acquire, so that the rows another CU / queue / GPU wrote while this launch was
     // resident are read from memory, not from this CU's L1.
-    if (hw.flag != nullptr && (r0 - (NS + sor::ring_rows(NS)) < hw.own_lo || r1 + NS + sor::ring_rows(NS) > hw.own_hi)) {  // wave-uniform
+    // "Reads a row" is meant in cache lines: when the row pitch is not a multiple of the line, the line that holds the first
+    // bytes of an owned row also holds the last bytes of the ghost row below it.  A tile that does NOT wait must not touch such
+    // a line either: its fill, requested before the message landed, can be installed in the CU's L1 after a waiting tile's
+    // acquire has invalidated it, and the waiting tile then reads the ghost row's old bytes from it (seen once in 26 k solves
+    // on 3000- and 2999-column slabs, never on pitches of whole lines: tools/r04/unaligned_stress.py).  Hence `line_rows`.
+    const int line_rows = (g.dim_x & 63) ? 1 + 63 / g.dim_x : 0;   // rows a 256-byte span reaches across a row boundary
+    const int reach = NS + sor::ring_rows(NS) + line_rows;
+    if (hw.flag != nullptr && (r0 - reach < hw.own_lo || r1 + reach > hw.own_hi)) {  // wave-uniform
         const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
         bool arrived = true;
         while ((int)((unsigned)__hip_atomic_load(hw.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)hw.epoch) < 0) {
@@ -473,6 +486,9 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         if (!arrived && lane == 0) atomicOr(hw.timed_out, 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+
+    // a SENDER tile (kernels.h HaloWait::done): its output rows are part of the next halo message
+    const bool sender = hw.done != nullptr && (r0 < hw.send_lo_end || r1 > hw.send_hi_begin);   // wave-uniform
 
     const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
     const unsigned records = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
@@ -491,7 +507,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bk.row_lo = max(g.grow0, 0);
         bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
         bk.row_sign = 1;
-        bk.prio_on = t.rotate;
+        bk.prio_on = sender ? 2 : t.rotate;   // senders first: the message is waiting for them
         bk.start_turns();
         bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
 #ifdef SFL_PROBE_COOP
@@ -526,6 +542,18 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
+    }
+    if (sender) {
+        // This wave's rows must be in memory before it counts itself: the copy / send kernel that picks them up runs on any
+        // XCD, or on another GPU.  Written-through stores (B::kStoreAux == 16) only have to be waited for -- every storing
+        // wave drains its own (CDNA guide, inter-workgroup rules R1); plain stores (odd widths: the 4-byte path) need the
+        // XCD's L2 written back, with the wait restated where the compiler cannot drop it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (B::kStoreAux != 16) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) __hip_atomic_fetch_add(hw.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef SFL_SOR_TRACE
     __builtin_amdgcn_s_waitcnt(0);  // the wave's stores have left
@@ -601,7 +629,7 @@ int auto_rows_per_chunk(const Slab &g, int g_begin, int g_end, int ns, int waves
 
 template <class B, int NS, bool DX1, bool ZERO_IN>
 hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                          SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
+                          SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
     auto tiling = [&](int g_begin, int g_end) {
         if (g_end <= g_begin) {
@@ -623,53 +651,65 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     // launch with and without), and a thin slab's launches run next to the halo exchange's kernels, which should
     // not have to compete with raised priorities
     t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE
-                            : rows.urgent ? 2
                                           : tiles <= resident_waves<B, NS, DX1, ZERO_IN>() && 2 * tiles > 5 * device_simds();
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0};
+    const HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0};
+    if (senders) {   // the same test as the kernel's, on the same tilings
+        int n = 0;
+        if (hw.done)
+            for (const sor::Tiling *t : {&t1, &t2})
+                for (int k = 0; k < t->n_tiles; ++k) {
+                    const sor::TileRect r = sor::tile_rect(*t, k);
+                    n += r.r0 < hw.send_lo_end || r.r1 > hw.send_hi_begin;
+                }
+        *senders = n;
+    }
     sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm, hw);
     return hipGetLastError();
 }
 
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
     // (a translation unit may hold only the dx == 1 kernels or only the general ones: SFL_DX_PART)
 #if SFL_DX_PART != 1
     if (prm.dx == 1.0f)
-        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+        return launch_variant<B, NS, true, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 #endif
 #if SFL_DX_PART != 0
     if (prm.dx != 1.0f)
-        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+        return launch_variant<B, NS, false, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 #endif
     return hipErrorInvalidValue;
 }
 
 template <int NS, bool ZERO_IN>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                       SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
+                       SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(p_out) | reinterpret_cast<uintptr_t>(p_in) |
                           reinterpret_cast<uintptr_t>(d);
     const bool can2v = (g.dim_x % 2 == 0) && (all & 7) == 0;
     if (can2v) {
-        // non-temporal stores once the slab's arrays no longer fit the caches (see Lane2)
+        // written through when sender tiles publish rows of this launch while it runs (see Lane2)
+        if (wait && wait->done)
+            return launch_dx<Lane2<NS, true, ZERO_IN, 16>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        // non-temporal stores once the slab's arrays no longer fit the caches
         if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
-            return launch_dx<Lane2<NS, true, ZERO_IN, true>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+            return launch_dx<Lane2<NS, true, ZERO_IN, 2>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
     }
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 }
 
 template <int NS>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
-                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
+                     SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 }
 
 }  // namespace
@@ -681,11 +721,11 @@ hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float
 #endif
 #define SFL_ENTRY_ARGS                                                                             \
     hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, SorParams prm, \
-        int rows_per_chunk, int sweep, const HaloWait *wait
+        int rows_per_chunk, int sweep, const HaloWait *wait, int *senders
 #define SFL_DEFINE_PART(N, P)                                                                      \
     hipError_t launch_sor_fused_ns##N##_p##P(SFL_ENTRY_ARGS)                                       \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);   \
+        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);   \
     }
 #if SFL_DX_PART == 0
 #define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0)
@@ -721,8 +761,9 @@ SFL_DEFINE_NS(16)
 #if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
-                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait)
+                            SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
+    if (senders) *senders = 0;
     if (rows.g_end <= rows.g_begin && rows.g2_end <= rows.g2_begin) return hipSuccess;
     if (first_colour != 0 || nsweeps < 2 || nsweeps > SFL_MAX_FUSE || (nsweeps & 1) ||
         p_out == p_in || p_out == nullptr || d == nullptr)
@@ -730,8 +771,8 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
     const bool dx1 = prm.dx == 1.0f;
 #define SFL_CASE(N)                                                                                              \
     case N:                                                                                                      \
-        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait)    \
-                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait);
+        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders) \
+                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }

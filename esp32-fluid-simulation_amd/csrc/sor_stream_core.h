@@ -344,7 +344,7 @@ struct Tiling {
     int n_tiles;
     int tile_cols, halo_cols;
     int rotate;           // GPU backend, set by the launcher: 1 = the waves of a SIMD take turns at the top issue priority,
-                          // 2 = every wave at the top priority throughout (an urgent launch)
+                          // (2 = this wave at the top priority throughout: set per tile by the kernel for sender tiles)
     int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect):
                           // 1 = the odd chunks, 2 = the even ones, 0 = none
 };

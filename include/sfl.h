@@ -110,12 +110,16 @@ extern "C" {
                                      back by this many microseconds on the exchange stream before its copy
                                      starts -- the latency of a real xGMI send / receive that a self-copy does
                                      not have; 0 (default) .. 10000                                   */
-#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, early exchanges: 1 (default) = the launch that needs a halo is queued
-                                     without waiting for the exchange stream; only its tiles next to a cut wait, INSIDE
-                                     the launch, on a device-side count of arrived messages (no cross-stream event on
-                                     the compute stream: the rest of the launch overlaps the tail of the exchange);
-                                     a wait of more than 2 s gives up and is reported by sfl_synchronize.
-                                     0 = the whole launch waits for an event of the exchange stream              */
+#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, with SFL_OPT_SOR_OVERLAP: 1 (default) = exchanges IN TIME, counted on the device
+                                     (sfl_plan_poisson kernel 3): the halo of a superstep is exchanged after the launch that
+                                     produces it; that launch runs the tiles whose rows the message carries at the top priority,
+                                     writes through, and counts them; the message leaves on that count while the rest of the
+                                     launch is still running; the next launch is queued at once and only its tiles next to a
+                                     cut wait, INSIDE the launch, for a count of arrived messages -- no event on the compute
+                                     stream, no launch on the ghost rows, no launch split.  A wait of more than 2 s gives up
+                                     and is reported by sfl_synchronize.
+                                     0 = early exchanges behind cross-stream events (round 3): the halo travels one launch
+                                     early, its ghost rows are relaxed behind the message, the launch after waits whole   */
 #define SFL_OPT_STEP_SEAMS 14      /* sfl_step_n on a whole-domain context with the tile kernels: 1 (default) = between two steps
                                      subtract_gradient + dye advection of one and velocity advection + divergence of the
                                      next run as ONE kernel (the projected velocity in between is never written to memory);
@@ -180,6 +184,9 @@ typedef struct sfl_plan_step {
  * the GPU executor walks exactly this program.                                               */
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
                              int halo, sfl_plan_step *steps, int cap, int *n_steps);
+/* kernel = 3: kernel 2's launches with IN-TIME exchanges at every halo depth -- never early: the exchange of a superstep
+ * follows the launch that produces its rows (SFL_OPT_SOR_ARRIVAL; with a tail every superstep holds halo - tail passes and its
+ * exchange skips the `tail` ghost rows the launch before left exact).                                                    */
 /* The same with a TAIL: `tail` ghost rows of p are still exact when the solve ends (every launch of an
  * early-exchange plan then extends that much further into the ghost rows; ignored -- as 0 -- by the other
  * plans).  sfl_step on slabs asks for 1, the row subtract_gradient (finitediff.cpp:41-82) reads beyond a

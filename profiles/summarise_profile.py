@@ -25,12 +25,13 @@ def tail_of(v):
 def short(name):
     import re
     # sor_fused_kernel<Lane2<NS, VEC, ZERO_IN[, NT]> | Lane4<NS, ZERO_IN>, NS, DX1, ZERO_IN>
-    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)>, \d+, (true|false), (true|false)>", name)
+    # (the store policy ST is an int since round 4 -- 0 plain, 2 nt, 16 sc1 -- and was a bool NT before)
+    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)(?:, (\d+))?>, \d+, (true|false), (true|false)>", name)
     if m:
         flags = [f == "true" for f in re.findall(r"true|false", m.group(3))]
-        nt = m.group(1) == "2" and len(flags) >= 3 and flags[2]
-        return (f"sor_fused_kernel<Lane{m.group(1)}{'nt' if nt else ''}, NS={m.group(2)}, dx1={m.group(4)}, "
-                f"zero_in={m.group(5)}>")
+        st = {"2": "nt", "16": "sc1"}.get(m.group(4) or "", "nt" if (m.group(1) == "2" and len(flags) >= 3 and flags[2]) else "")
+        return (f"sor_fused_kernel<Lane{m.group(1)}{st}, NS={m.group(2)}, dx1={m.group(5)}, "
+                f"zero_in={m.group(6)}>")
     m = re.search(r"(advect_divergence_tiled_kernel|advect_vec2f_tiled_kernel|advect_vec3uq32_tiled_kernel)<([^>]*)>", name)
     if m:
         flags = re.findall(r"true|false", m.group(2))

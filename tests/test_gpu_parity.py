@@ -14,13 +14,14 @@ DT = np.float32(1 / 30.0)
 OMEGA = np.float32(1.96)
 
 
-def plan_exchanges(sfl, dim_y, nranks, iters, fuse, halo=0):
+def plan_exchanges(sfl, dim_y, nranks, iters, fuse, halo=0, kernel=3):
     """Halo exchanges of one fused-kernel solve as the library plans it with an automatic (0) or given halo:
-    counted on the program sfl_plan_poisson returns (csrc/sfl_api.cpp effective_halo restated)."""
+    counted on the program sfl_plan_poisson returns (csrc/sfl_api.cpp effective_halo restated).  kernel 3 = exchanges in
+    time (the default executor, SFL_OPT_SOR_ARRIVAL), 2 = early exchanges where the halo is deep enough."""
     rows = min(b - a for a, b in (sfl.slab_rows(dim_y, nranks, r) for r in range(nranks)))
     h = halo or (64 if rows >= 1024 else 32)
     h = max(min(h, rows, 64), fuse)
-    return sum(st.kind == sfl.capi.STEP_EXCHANGE for st in sfl.plan_poisson(dim_y, nranks, 0, iters, fuse, 2, h))
+    return sum(st.kind == sfl.capi.STEP_EXCHANGE for st in sfl.plan_poisson(dim_y, nranks, 0, iters, fuse, kernel, h))
 
 
 @pytest.fixture(scope="module")
@@ -679,6 +680,7 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
     infos = []
     # overlapped with the halo's arrival signalled on the device (the default: cut-adjacent tiles wait inside the
     # launch), overlapped with a cross-stream event in front of the launch, in line
+    # in time, counted on the device (the default); early behind cross-stream events; in line
     for overlap, arrival in ((1, 1), (1, 0), (0, 1)):
         slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
         try:
@@ -697,13 +699,14 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
         finally:
             for s in slabs:
                 s.close()
-        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}, arrival by flag {arrival}")
-    assert infos[0] == infos[1] == infos[2] and infos[0]["exchanges"] > 0
+        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}, arrival counted on the device {arrival}")
+    # (in time and in line walk the same kernel-3 program; the early program has the same launches)
+    assert infos[0]["launches"] == infos[1]["launches"] == infos[2]["launches"] and all(i["exchanges"] > 0 for i in infos)
 
 
 def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
-    """SFL_OPT_SOR_ARRIVAL: the launch that needs a halo is queued without a cross-stream event; its cut-adjacent tiles
-    poll a device-side arrival count and acquire.  Many solves back to back on 8 virtual ranks of a grid wide enough
+    """SFL_OPT_SOR_ARRIVAL: exchanges in time -- the message leaves on a device-side count of the launch's sender tiles, the
+    next launch is queued without a cross-stream event and its cut-adjacent tiles poll an arrival count and acquire.  Many solves back to back on 8 virtual ranks of a grid wide enough
     that the launches fill the chip (the polling tiles' CUs are busy and L1-warm from the previous launch, the exchange
     stream's copies and ghost-row launches run beside them), every solve's result against the oracle."""
     dim_x, dim_y, nranks, iters = 4096, 2048, 8, 31
@@ -714,6 +717,7 @@ def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
         slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 10)
         assert slabs[3].get_option(sfl.capi.OPT_SOR_ARRIVAL) == 1
         for rep in range(3):
+            slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, 0 if rep == 1 else 1)   # (early exchanges behind events in the middle repetition)
             d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
             for s in slabs:
                 s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
@@ -776,8 +780,8 @@ def test_baseline_config5_slab_program_vs_oracle(sfl, oracle):
     finally:
         for s in slabs:
             s.close()
-    # the rhs + seven early p exchanges (supersteps of three launches behind the first of four)
-    assert info["fuse"] == 16 and info["launches"] == 25 and info["exchanges"] == 8 == plan_exchanges(sfl, dim_y, nranks, iters, 16)
+    # the rhs + six in-time p exchanges (supersteps of four launches: 64 passes per 64-row halo)
+    assert info["fuse"] == 16 and info["launches"] == 25 and info["exchanges"] == 7 == plan_exchanges(sfl, dim_y, nranks, iters, 16)
     assert_bit_equal(got, want, "C5 slab program: 16384 x 4096 in two slabs, 200 iterations")
 
 

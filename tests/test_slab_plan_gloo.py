@@ -157,3 +157,33 @@ def test_slab_program_with_a_tail_over_gloo(tmp_path, oracle, world, fuse, iters
     prog = sfl.plan_poisson(dim_y, world, 0, iters, fuse, 2, halo, tail)
     last = [s for s in prog if s.kind == sfl.capi.STEP_SOR][-1]
     assert last.g_end - sfl.slab_rows(dim_y, world, 0)[1] == (tail if has_tail else 0)
+
+
+@pytest.mark.parametrize("world,fuse,iters,halo,tail", [(2, 10, 40, 64, 0), (2, 10, 40, 64, 1), (3, 6, 20, 30, 3), (2, 8, 12, 16, 1),
+                                                       (3, 4, 7, 4, 0), (2, 16, 24, 64, 1)])
+def test_in_time_slab_program_over_gloo(tmp_path, oracle, world, fuse, iters, halo, tail):
+    """sfl_plan_poisson kernel 3 (what SFL_OPT_SOR_ARRIVAL runs): the fused launches with in-time exchanges at EVERY halo depth --
+    the exchange of a superstep follows the launch that produces its rows, never precedes it -- with and without a tail
+    (every superstep then holds halo - tail passes, the exchange skips the tail rows that are still exact).  Executed by
+    gloo ranks with NaN ghosts: owned rows and tail rows must hold the reference's values."""
+    import torch.multiprocessing as mp
+    dim_x, dim_y = 37, 140
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, dim_x, dim_y, iters, fuse, 3, halo, str(tmp_path), tail),
+             nprocs=world, join=True)
+    d_full = np.random.default_rng(99).standard_normal((dim_y, dim_x)).astype(np.float32)
+    want = oracle.poisson_solve(d_full, 1.0, iters, OMEGA)
+    sfl = importlib.import_module("esp32-fluid-simulation_amd")
+    has_tail = max(halo, fuse) >= fuse + tail
+    for r in range(world):
+        g0, g1 = sfl.slab_rows(dim_y, world, r)
+        assert_bit_equal(np.load(tmp_path / f"p_{r}.npy"), want[g0:g1], f"rank {r}: owned rows")
+        if has_tail and tail:
+            lo_t, hi_t = (tail if r > 0 else 0), (tail if r < world - 1 else 0)
+            assert_bit_equal(np.load(tmp_path / f"pt_{r}.npy"), want[g0 - lo_t:g1 + hi_t], f"rank {r}: owned rows + tail")
+    prog = sfl.plan_poisson(dim_y, world, 0, iters, fuse, 3, halo, tail)
+    cap = sfl.capi
+    kinds = [s.kind for s in prog]
+    for k, st in enumerate(prog):   # never early: every p exchange starts at the cut (or behind the tail) and follows a launch
+        if st.kind == cap.STEP_EXCHANGE and st.field == cap.FIELD_PRESSURE:
+            assert st.g_begin == (tail if has_tail else 0) and kinds[k - 1] == cap.STEP_SOR and kinds[k + 1] == cap.STEP_SOR

@@ -85,7 +85,7 @@ int main(int argc, char **argv)
     const int alternate = getenv("PROBE_ALTERNATE") ? atoi(getenv("PROBE_ALTERNATE")) : 0;
     int n_launch = 0;
     auto launch = [&](float *out, const float *in) {
-        return sfl::PROBE_LAUNCH(st, out, in, d, g, rows, prm, rpc, alternate ? n_launch++ : 0, nullptr);
+        return sfl::PROBE_LAUNCH(st, out, in, d, g, rows, prm, rpc, alternate ? n_launch++ : 0, nullptr, nullptr);
     };
 
     if (loop_s > 0) {  // a steady load for clock polling from outside (rocm-smi / amd-smi)
