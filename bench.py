@@ -286,6 +286,9 @@ def parse_args(argv=None):
                     help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
+    ap.add_argument("--chain", type=int, default=None, choices=(0, 1),
+                    help="SFL_OPT_SOR_CHAIN: 1 = the launches of a solve as chained launches (waves go from one superstep to the "
+                         "next, tiles wait for the tiles around them), 0 = one launch per superstep; default: the library's")
     ap.add_argument("--arrival-by-event", action="store_true",
                     help="SFL_OPT_SOR_ARRIVAL = 0: early halo exchanges behind cross-stream events (round 3's scheme) instead of "
                          "in-time exchanges counted on the device (A/B)")
@@ -432,6 +435,8 @@ def run_rank(args):
         s.set_option(capi.OPT_SOR_OVERLAP, 0)
     if args.arrival_by_event:
         s.set_option(capi.OPT_SOR_ARRIVAL, 0)
+    if args.chain is not None:
+        s.set_option(capi.OPT_SOR_CHAIN, args.chain)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
                      (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
                      (capi.OPT_SOR_HALO, args.sor_halo), (capi.OPT_ADVECT_KERNEL, args.advect_kernel)):

@@ -105,6 +105,9 @@ struct sfl_context {
     int arrival_epoch = 0;         // the last value queued for [1]
     int *d_done = nullptr;         // [3] sender tiles finished so far (kernels.h HaloWait::done): what the exchange stream waits
     int done_target = 0;           //     for before a halo message leaves; done_target = the count the launches queued so far reach
+    int *d_chain = nullptr;        // one word per tile of a chained launch (kernels.h launch_sor_chain), allocated on first use
+    int chain_words = 0;
+    int chain_epoch = 0;           // the words only count up: the next chained launch starts from here
 
     // queued point forces (ino:264-269)
     std::vector<int> force_cells;
@@ -152,7 +155,7 @@ struct sfl_context {
 
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
-        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1, opt_step_seams = 1;
+        opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = 1, opt_step_seams = 1, opt_sor_chain = 0;
 
     ncclComm_t comm = nullptr;
     bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
@@ -468,6 +471,61 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
     return SFL_OK;
 }
 
+// ---- chained supersteps (kernels.h launch_sor_chain; SFL_OPT_SOR_CHAIN) ---------------------------------------------------
+// May plan steps [i, i + n) of `prog` go into one chained launch?  SOR steps of one supported fuse depth, none from zero.
+int chainable_steps(const sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, bool across_exchanges)
+{
+    if (!c->opt_sor_chain || effective_kernel(c) != 2) return 0;
+    int n = 0;
+    size_t k = i;
+    for (; k < prog.size() && n < sfl::kMaxChain; ++k) {
+        const sfl_plan_step &st = prog[k];
+        if (st.kind == SFL_STEP_EXCHANGE && across_exchanges && st.field == SFL_FIELD_PRESSURE && n > 0) continue;
+        if (st.kind != SFL_STEP_SOR || st.from_zero || st.first_colour != 0 || st.nsweeps != prog[i].nsweeps ||
+            st.g_end <= st.g_begin)
+            break;
+        ++n;
+    }
+    if (n < 2 || !sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, prog[i].nsweeps)) return 0;
+    return n;
+}
+
+int ensure_chain_words(sfl_context *c)
+{
+    if (c->d_chain) return SFL_OK;
+    // more words than any tiling of the slab has tiles: strips of >= 96 kept columns x chunks of >= kMinEdgeRows rows
+    const int words = 32 * (c->dim_x / 96 + 3) * (c->geom.lrows / 8 + 4);   // a 128-byte line per tile
+    void *m = nullptr;
+    SFL_TRY(use_device(c));
+    HIP_TRY(hipMalloc(&m, (size_t)words * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(m, 0, (size_t)words * sizeof(int), c->stream));
+    c->d_chain = static_cast<int *>(m);
+    c->chain_words = words;
+    return SFL_OK;
+}
+
+// Plan steps [i, i + n) of a context whose launches need no halo protocol (whole domains, the in-line order), as one launch.
+int exec_sor_chain(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, int n, const sfl::SorParams &prm)
+{
+    SFL_TRY(ensure_chain_words(c));
+    sfl::ChainStep steps[sfl::kMaxChain];
+    for (int k = 0; k < n; ++k) {
+        const sfl_plan_step &st = prog[i + k];
+        steps[k].g_begin = st.g_begin;
+        steps[k].g_end = st.g_end;
+        steps[k].sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + k : 0;
+        steps[k].hw = sfl::HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0};
+        steps[k].guard_flag = nullptr;
+        steps[k].guard_epoch = steps[k].guard_lo_end = steps[k].guard_hi_begin = 0;
+    }
+    HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, prog[i].nsweeps, prm, c->opt_sor_rows,
+                                  c->d_chain, c->chain_words, c->chain_epoch, c->d_arrival + 1, 0, nullptr));
+    c->chain_epoch += n + 1;
+    if (n & 1) std::swap(c->p, c->p_alt);
+    c->last_launches += n;
+    return SFL_OK;
+}
+
 // The exchange stream and its two events (created on first use): the group's when the contexts are
 // linked, the context's own otherwise.
 struct Overlap {
@@ -534,6 +592,97 @@ int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, i
     return await_exchange(peers, o);
 }
 
+// The rows the last p halo message of a solve was read from, and how many supersteps have been issued since: the superstep
+// two behind a message overwrites its source (kernels.h ChainStep::guard_flag).
+struct SentBand {
+    bool valid = false;
+    int epoch = 0, lo_end = 0, hi_begin = 0, age = 0;
+};
+
+// In-time exchanges with the launches CHAINED (SFL_OPT_SOR_CHAIN): the SOR steps from prog[i] on -- up to kMaxChain, p exchanges
+// between and behind them included -- as one chained launch on the compute stream, with the exchange stream's work (wait for
+// the sender count, copy / send, raise the arrival count) queued behind it exactly as for single launches.  One context only:
+// the chains of several virtual ranks on one stream would wait for each other's messages in vain.  *next = first plan step not
+// consumed (== i: nothing was chained).
+int chain_in_time(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, const sfl::SorParams &prm, const Overlap &o,
+                  bool *flagged, SentBand *band, size_t *next)
+{
+    *next = i;
+    const std::vector<sfl_context *> self{c};
+    std::vector<size_t> sor;
+    std::vector<long> xch;   // the p exchange behind sor[k] (index into prog), or -1
+    size_t k = i;
+    const int ns = prog[i].nsweeps;
+    while (k < prog.size() && (int)sor.size() < sfl::kMaxChain) {
+        const sfl_plan_step &st = prog[k];
+        if (st.kind != SFL_STEP_SOR || st.from_zero || st.first_colour != 0 || st.nsweeps != ns || st.g_end <= st.g_begin) break;
+        sor.push_back(k++);
+        if (k < prog.size() && prog[k].kind == SFL_STEP_EXCHANGE && prog[k].field == SFL_FIELD_PRESSURE)
+            xch.push_back((long)k++);
+        else
+            xch.push_back(-1);
+    }
+    const int n = (int)sor.size();
+    if (n < 2 || !sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, ns)) return SFL_OK;
+    SFL_TRY(ensure_chain_words(c));
+    sfl::ChainStep steps[sfl::kMaxChain];
+    int epoch = c->arrival_epoch;   // the value the arrival count reaches with the exchanges issued so far
+    bool fl = *flagged;
+    SentBand b = *band;
+    for (int q = 0; q < n; ++q) {
+        const sfl_plan_step &st = prog[sor[q]];
+        sfl::ChainStep &cs = steps[q];
+        cs.g_begin = st.g_begin;
+        cs.g_end = st.g_end;
+        cs.sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + q : 0;
+        cs.hw = arrival_wait(c);
+        cs.hw.epoch = epoch;
+        if (!fl) cs.hw.flag = nullptr;
+        ++b.age;
+        cs.guard_flag = b.valid && b.age == 2 ? c->d_arrival : nullptr;
+        cs.guard_epoch = b.epoch;
+        cs.guard_lo_end = b.lo_end;
+        cs.guard_hi_begin = b.hi_begin;
+        fl = false;
+        if (xch[q] >= 0) {
+            const sfl_plan_step &x = prog[xch[q]];
+            cs.hw.done = c->d_done;
+            cs.hw.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+            cs.hw.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+            ++epoch;
+            fl = true;
+            b.valid = true;
+            b.epoch = epoch;
+            b.lo_end = cs.hw.send_lo_end;
+            b.hi_begin = cs.hw.send_hi_begin;
+            b.age = 0;
+        }
+    }
+    int senders[sfl::kMaxChain] = {0};
+    // room for the exchange stream's kernels beside the chain: two waves per SIMD at most
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    SFL_TRY(use_device(c));
+    HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, ns, prm, c->opt_sor_rows, c->d_chain,
+                                  c->chain_words, c->chain_epoch, c->d_arrival + 1, cus * 8, senders));
+    c->chain_epoch += n + 1;
+    if (n & 1) std::swap(c->p, c->p_alt);
+    c->last_launches += n;
+    for (int q = 0; q < n; ++q) {
+        c->done_target += senders[q];
+        if (xch[q] < 0) continue;
+        const sfl_plan_step &x = prog[xch[q]];
+        HIP_TRY(sfl::launch_wait_count(o.xstream, c->d_done, c->done_target, c->d_arrival + 1));
+        SFL_TRY(exchange(self, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin));
+        SFL_TRY(signal_arrival(self, o.xstream));
+    }
+    *flagged = fl;
+    *band = b;
+    *next = k;
+    return SFL_OK;
+}
+
 // Exchanges IN TIME (slab_plan.cpp kernel 3; SFL_OPT_SOR_ARRIVAL): the halo of a superstep is sent after the launch that
 // produces it, as in the textbook -- but nothing waits for a whole launch any more.  The launch in front of an exchange
 // marks the tiles whose rows the message carries as SENDERS (top priority; each counts itself once its rows are written
@@ -545,6 +694,7 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
                         const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
 {
     bool flagged = false;   // the next launch's cut-adjacent tiles wait for the arrival count
+    SentBand band;          // the last p message's source rows (chained launches)
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -554,6 +704,15 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             flagged = true;
             continue;
         }
+        if (peers.size() == 1 && ctx->opt_sor_chain && !st0.from_zero) {
+            size_t next = i;
+            SFL_TRY(chain_in_time(ctx, progs[0], i, prm, o, &flagged, &band, &next));
+            if (next > i) {
+                i = next - 1;
+                continue;
+            }
+        }
+        ++band.age;
         const bool sends = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE && progs[0][i + 1].field == SFL_FIELD_PRESSURE;
         for (size_t k = 0; k < peers.size(); ++k) {
             sfl_context *c = peers[k];
@@ -583,6 +742,11 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin));
             SFL_TRY(signal_arrival(peers, o.xstream));
             flagged = true;
+            band.valid = true;
+            band.epoch = ctx->arrival_epoch;
+            band.lo_end = ctx->rank > 0 ? ctx->g0 + x.g_begin + x.rows : -(1 << 30);
+            band.hi_begin = ctx->rank < ctx->nranks - 1 ? ctx->g1 - x.g_begin - x.rows : (1 << 30);
+            band.age = 0;
             ++i;   // the exchange step has been issued
         }
     }
@@ -777,6 +941,9 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
             const sfl_plan_step &st0 = progs[0][i];
             if (st0.kind == SFL_STEP_EXCHANGE) {
                 SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
+            } else if (const int n = chainable_steps(ctx, progs[0], i, false)) {   // same program shape on every peer
+                for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_chain(peers[k], progs[k], i, n, prm));
+                i += n - 1;
             } else {
                 for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
             }
@@ -1062,7 +1229,7 @@ int sfl_destroy(sfl_context *c)
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);  // nothing of the communicator may still be queued
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
-                    (void *)c->sor_block, (void *)c->halo_flag,
+                    (void *)c->sor_block, (void *)c->halo_flag, (void *)c->d_chain,
                     (void *)c->d_force_cells, (void *)c->d_force_vel, (void *)c->d_image,
                     (void *)c->host_scratch, (void *)c->d_reach, c->gather_buf})
         if (m) (void)hipFree(m);
@@ -1137,6 +1304,9 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_STEP_SEAMS:
             c->opt_step_seams = value ? 1 : 0;
             return SFL_OK;
+        case SFL_OPT_SOR_CHAIN:
+            c->opt_sor_chain = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
                 return fail(SFL_ERR_INVALID, "SOR halo must be 0 (auto) or 2..%d rows", kGhostRows);
@@ -1186,6 +1356,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_EMULATE_WIRE_US: *value = c->opt_emulate_wire_us; return SFL_OK;
         case SFL_OPT_SOR_ARRIVAL: *value = c->opt_sor_arrival; return SFL_OK;
         case SFL_OPT_STEP_SEAMS: *value = c->opt_step_seams; return SFL_OK;
+        case SFL_OPT_SOR_CHAIN: *value = c->opt_sor_chain; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }

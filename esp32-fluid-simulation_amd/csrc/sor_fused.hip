@@ -192,7 +192,9 @@ struct WaveCommon {
 // while the launch is still running: with plain stores every sender would have to write back its XCD's whole L2 first
 // (buffer_wbl2: the launch took 48 instead of 24 us), written-through rows only have to be waited for (8192 x 1024: +0.5 %
 // for the launch, profiles/r04_experiments_without_gain.txt 3).
-template <int NS, bool VEC, bool ZERO_IN, int ST = 0>
+// LD = cache policy of the p loads (VEC only): 0 plain; 16 = sc1, past the CU's L1 -- the chained launch (sor_chain_kernel), whose
+// tiles read rows that other CUs stored (written-through) while the launch is running.
+template <int NS, bool VEC, bool ZERO_IN, int ST = 0, int LD = 0>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
@@ -266,7 +268,7 @@ struct Lane2 : WaveCommon {
         }
         if (!ZERO_IN) {
             if (VEC) {
-                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, SFL_PROBE_P_LOAD_AUX));
+                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, SFL_PROBE_P_LOAD_AUX ? SFL_PROBE_P_LOAD_AUX : LD));
                 pa = q.x;
                 pb = q.y;
             } else {
@@ -420,6 +422,70 @@ struct Lane2 : WaveCommon {
 #endif
 constexpr int min_waves_per_simd(int ns) { return ns == 14 ? 2 : ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }
 
+// One tile: its NS passes over output rows rect.[r0, r1) of strip rect.strip, from p_in (ZERO_IN: from zero) to p_out.
+// Returns the path taken (0 interior bottom-up, 1 boundary, 2 interior top-down).
+template <class B, int NS, bool DX1, bool ZERO_IN>
+__device__ __forceinline__ int relax_tile(float *p_out, const float *p_in, const float *d, const Slab &g, const sor::Tiling &t,
+                                          const sor::TileRect &rect, const SorParams &prm, bool sender, float *ring_base, int lane
+#ifdef SFL_PROBE_COOP
+                                          , float *coop_mem, int wave
+#endif
+                                          )
+{
+    const int x0 = sor::strip_x0(t, rect.strip);
+    const int r0 = rect.r0, r1 = rect.r1;
+    const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
+    const unsigned records = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+    // The backend (buffer resources, lane offsets) is built inside each branch: built once in
+    // front of the branch, its SGPRs live through the register-hungry boundary path too and the
+    // allocator parks the store's descriptor in spill lanes, reloading it for every row of the
+    // interior path as well (8 v_readlane / v_writelane per row, 6 % of its VALU-class instructions).
+    auto backend = [&]() {
+        B bk;
+        bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
+        bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
+        bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
+        bk.dim_x = g.dim_x;
+        bk.gdim_y = g.gdim_y;
+        bk.grow0 = g.grow0;
+        bk.row_lo = max(g.grow0, 0);
+        bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
+        bk.row_sign = 1;
+        bk.prio_on = sender ? 2 : t.rotate;   // senders first: the message is waiting for them
+        bk.start_turns();
+        bk.setup(ring_base, lane, x0, t.halo_cols);
+#ifdef SFL_PROBE_COOP
+        bk.coop_is_pub = lane == 1 || lane == 62;
+        bk.coop_is_ghost = lane == 0 || lane == 63;
+        bk.coop_pub = coop_mem + wave * 2 + (lane == 62);
+        // lane 0 picks up what the wave on its left published from lane 62, lane 63 what the wave on its right did from lane 1
+        bk.coop_get = coop_mem + ((wave + (lane == 0 ? kWavesPerBlock - 1 : 1)) % kWavesPerBlock) * 2 + (lane == 0);
+#endif
+        return bk;
+    };
+    if (!SFL_PROBE_NO_EDGE && sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
+        B bk = backend();
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        const auto eca = bk.edge_cell(lane, x0, 0);
+        const auto ecb = bk.edge_cell(lane, x0, 1);
+        sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
+        return 1;
+    }
+    if (sor::tile_may_flip(t, rect)) {  // streamed top-down: pipeline index = -row
+        B bk = backend();
+        bk.row_sign = -1;
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        const sor::EdgeCell<B> none{};
+        sor::stream_tile<B, NS, false, DX1, ZERO_IN, true>(bk, c, none, none, 1 - r1, 1 - r0);
+        return 2;
+    }
+    B bk = backend();
+    sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+    const sor::EdgeCell<B> none{};
+    sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
+    return 0;
+}
+
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t1,
@@ -458,7 +524,6 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     const sor::Tiling t = second ? t2 : t1;
     if (second) tile -= t1.n_tiles;
     const sor::TileRect rect = sor::tile_rect(t, tile);
-    const int x0 = sor::strip_x0(t, rect.strip);
     const int r0 = rect.r0, r1 = rect.r1;
 
     // Halo arrival inside the launch (kernels.h HaloWait): a tile that reads a row a halo message writes -- in either
@@ -490,59 +555,16 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // a SENDER tile (kernels.h HaloWait::done): its output rows are part of the next halo message
     const bool sender = hw.done != nullptr && (r0 < hw.send_lo_end || r1 > hw.send_hi_begin);   // wave-uniform
 
-    const size_t bytes = (size_t)g.lrows * (size_t)g.dim_x * 4;
-    const unsigned records = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
-    // The backend (buffer resources, lane offsets) is built inside each branch: built once in
-    // front of the branch, its SGPRs live through the register-hungry boundary path too and the
-    // allocator parks the store's descriptor in spill lanes, reloading it for every row of the
-    // interior path as well (8 v_readlane / v_writelane per row, 6 % of its VALU-class instructions).
-    auto backend = [&]() {
-        B bk;
-        bk.rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ZERO_IN ? d : p_in), 0, records, 0x00020000);
-        bk.rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d), 0, records, 0x00020000);
-        bk.rs_out = __builtin_amdgcn_make_buffer_rsrc(p_out, 0, records, 0x00020000);
-        bk.dim_x = g.dim_x;
-        bk.gdim_y = g.gdim_y;
-        bk.grow0 = g.grow0;
-        bk.row_lo = max(g.grow0, 0);
-        bk.row_hi = min(g.grow0 + g.lrows, g.gdim_y);
-        bk.row_sign = 1;
-        bk.prio_on = sender ? 2 : t.rotate;   // senders first: the message is waiting for them
-        bk.start_turns();
-        bk.setup(ring_mem[wave], lane, x0, t.halo_cols);
 #ifdef SFL_PROBE_COOP
-        bk.coop_is_pub = lane == 1 || lane == 62;
-        bk.coop_is_ghost = lane == 0 || lane == 63;
-        bk.coop_pub = coop_mem + wave * 2 + (lane == 62);
-        // lane 0 picks up what the wave on its left published from lane 62, lane 63 what the wave on its right did from lane 1
-        bk.coop_get = coop_mem + ((wave + (lane == 0 ? kWavesPerBlock - 1 : 1)) % kWavesPerBlock) * 2 + (lane == 0);
+    const int kind = relax_tile<B, NS, DX1, ZERO_IN>(p_out, p_in, d, g, t, rect, prm, sender, ring_mem[wave], lane, coop_mem, wave);
+#else
+    const int kind = relax_tile<B, NS, DX1, ZERO_IN>(p_out, p_in, d, g, t, rect, prm, sender, ring_mem[wave], lane);
 #endif
-        return bk;
-    };
-    if (!SFL_PROBE_NO_EDGE && sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
-        B bk = backend();
-        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
-        const auto eca = bk.edge_cell(lane, x0, 0);
-        const auto ecb = bk.edge_cell(lane, x0, 1);
-        sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
 #ifdef SFL_SOR_TRACE
-        trace_kind = 1;
+    trace_kind = kind;
+#else
+    (void)kind;
 #endif
-    } else if (sor::tile_may_flip(t, rect)) {  // streamed top-down: pipeline index = -row
-        B bk = backend();
-        bk.row_sign = -1;
-        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
-        const sor::EdgeCell<B> none{};
-        sor::stream_tile<B, NS, false, DX1, ZERO_IN, true>(bk, c, none, none, 1 - r1, 1 - r0);
-#ifdef SFL_SOR_TRACE
-        trace_kind = 2;
-#endif
-    } else {
-        B bk = backend();
-        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
-        const sor::EdgeCell<B> none{};
-        sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
-    }
     if (sender) {
         // This wave's rows must be in memory before it counts itself: the copy / send kernel that picks them up runs on any
         // XCD, or on another GPU.  Written-through stores (B::kStoreAux == 16) only have to be waited for -- every storing
@@ -559,6 +581,139 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     __builtin_amdgcn_s_waitcnt(0);  // the wave's stores have left
     trace.end(trace_tile, trace_kind);
 #endif
+}
+
+// ---- chained supersteps (kernels.h launch_sor_chain) ---------------------------------------------------------------------
+// What a launch boundary costs a thin slab: 2.4-3.9 us of dispatch / drain per launch of 20 us, and a SIMD whose older wave
+// has finished runs its younger one alone, at 60 % of the pair's rate, for the last seventh of every launch
+// (profiles/r04_thin_share_lower_bound.txt).  Here a wave goes straight on to its tile of the next superstep; what it needs
+// from the previous superstep are the tiles within NS + 3 rows and one strip of its own.
+#ifndef SFL_PROBE_CHAIN_NO_DEPS
+#define SFL_PROBE_CHAIN_NO_DEPS 0   // diagnostic builds only: nobody waits for anybody (wrong results): the cost of the waits
+#endif
+#ifndef SFL_CHAIN_ST
+#define SFL_CHAIN_ST 16             // cache policy of the chain's p stores / loads (diagnostic builds: 0 = plain, wrong results)
+#endif
+#ifndef SFL_CHAIN_LD
+#define SFL_CHAIN_LD 16
+#endif
+#ifndef SFL_CHAIN_FLAG_STRIDE
+#define SFL_CHAIN_FLAG_STRIDE 32    // ints between the words of two tiles: a 128-byte line each
+#endif
+#ifndef SFL_CHAIN_SLEEP
+#define SFL_CHAIN_SLEEP 1
+#endif
+struct ChainLink {
+    sor::Tiling t;
+    HaloWait hw;
+    const int *guard_flag;
+    int guard_epoch, guard_lo_end, guard_hi_begin;
+};
+struct ChainArgs {
+    int n_steps, waves, epoch;
+    int *flags;
+    int *timed_out;
+    ChainLink link[kMaxChain];
+};
+
+// rows beyond its output rows that a tile touches, in either stream direction: NS rows of input, the row that makes the first
+// input row even, kPrefetch rows in flight past the last one -- and, on pitches that are not whole cache lines, the rows that
+// share a line with them (see the arrival wait of sor_fused_kernel)
+template <class B, int NS>
+__device__ __forceinline__ int chain_reach(const Slab &g)
+{
+    return NS + B::kPrefetch + ((g.dim_x & 63) ? 1 + 63 / g.dim_x : 0);
+}
+
+// Wait until every tile of tiling `prev` whose output rows intersect [lo, hi) in strips strip - 1 .. strip + 1 has published
+// `want` (or a later value).  Lane k polls the k-th such tile; one relaxed agent-scope load per lane and turn.
+__device__ __forceinline__ __attribute__((unused)) bool chain_wait(const sor::Tiling &prev, int strip, int lo, int hi, const int *flags, int want, int lane)
+{
+    int c0[3], n[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int c1;
+        if (sor::chunks_touching(prev, strip - 1 + k, lo, hi, &c0[k], &c1)) n[k] = c1 - c0[k] + 1;
+    }
+    const int total = n[0] + n[1] + n[2];   // wave-uniform
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
+    for (int base = 0; base < total; base += 64) {
+        const int k = base + lane;
+        int idx = -1;
+        if (k < n[0]) idx = sor::tile_index(prev, strip - 1, c0[0] + k);
+        else if (k < n[0] + n[1]) idx = sor::tile_index(prev, strip, c0[1] + k - n[0]);
+        else if (k < total) idx = sor::tile_index(prev, strip + 1, c0[2] + k - n[0] - n[1]);
+        for (;;) {
+            const bool behind = idx >= 0 && (int)((unsigned)__hip_atomic_load(flags + (size_t)idx * SFL_CHAIN_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) < 0;
+            if (!__builtin_amdgcn_ballot_w64(behind)) break;
+            __builtin_amdgcn_s_sleep(SFL_CHAIN_SLEEP);
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) return false;
+        }
+    }
+    return true;
+}
+
+template <class B, int NS, bool DX1>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
+sor_chain_kernel(float *pa, float *pb, const float *d, Slab g, SorParams prm, ChainArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // XCD-contiguous slots, as in sor_fused_kernel: slot k of every superstep is (nearly) the same rectangle, so a wave's
+    // neighbours in one superstep are its neighbours in the next, on the same XCD
+    const int nblocks = gridDim.x;
+    int block = blockIdx.x;
+    {
+        const int per = nblocks >> 3, rem = nblocks & 7;
+        const int xcd = block & 7, idx = block >> 3;
+        block = xcd * per + min(xcd, rem) + idx;
+    }
+    const int slot = block * kWavesPerBlock + wave;
+    if (slot >= a.waves) return;
+    const int reach = chain_reach<B, NS>(g);
+
+    for (int s = 0; s < a.n_steps; ++s) {
+        const sor::Tiling t = a.link[s].t;
+        const HaloWait hw = a.link[s].hw;
+        const float *p_in = (s & 1) ? pb : pa;
+        float *p_out = (s & 1) ? pa : pb;
+        for (int tile = slot; tile < t.n_tiles; tile += a.waves) {
+            const sor::TileRect rect = sor::tile_rect(t, tile);
+            const int r0 = rect.r0, r1 = rect.r1;
+            bool ok = true;
+            // the previous superstep's tiles around this one: their output is this tile's input, and this tile's output
+            // replaces their input (the two arrays take turns)
+            if (s > 0 && !SFL_PROBE_CHAIN_NO_DEPS)
+                ok = chain_wait(a.link[s - 1].t, rect.strip, r0 - reach, r1 + reach, a.flags, a.epoch + s, lane);
+            // the halo message of the exchange in front of this superstep (see sor_fused_kernel; no acquire: sc1 loads), and
+            // the message two supersteps back whose source this tile overwrites (kernels.h ChainStep::guard_flag)
+            const bool incoming = hw.flag != nullptr && (r0 - reach < hw.own_lo || r1 + reach > hw.own_hi);
+            const bool outgoing = a.link[s].guard_flag != nullptr && (r0 < a.link[s].guard_lo_end || r1 > a.link[s].guard_hi_begin);
+            if (incoming || outgoing) {
+                const int *word = incoming ? hw.flag : a.link[s].guard_flag;
+                const int want = incoming ? hw.epoch : a.link[s].guard_epoch;   // the later of the two when both apply
+                const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+                while ((int)((unsigned)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) < 0) {
+                    __builtin_amdgcn_s_sleep(20);
+                    if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            if (!ok && lane == 0) atomicOr(a.timed_out, 1);
+            const bool sender = hw.done != nullptr && (r0 < hw.send_lo_end || r1 > hw.send_hi_begin);
+            relax_tile<B, NS, DX1, false>(p_out, p_in, d, g, t, rect, prm, sender, ring_mem[wave], lane);
+            // publish: the rows are written through; once this wave's stores have left, the word may say so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(a.flags + (size_t)tile * SFL_CHAIN_FLAG_STRIDE, a.epoch + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sender) __hip_atomic_fetch_add(hw.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (sender) __builtin_amdgcn_s_setprio(0);
+        }
+    }
 }
 
 // Resident waves of one instantiation on the whole device (occupancy query, cached).
@@ -668,6 +823,63 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     return hipGetLastError();
 }
 
+template <class B, int NS, bool DX1>
+hipError_t launch_chain_variant(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
+                                SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out,
+                                int max_waves, int *senders)
+{
+    static int resident = 0;   // waves of this kernel the device holds at once
+    if (!resident) {
+        int dev = 0, cus = 0, blocks = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, sor_chain_kernel<B, NS, DX1>, kThreads, 0) != hipSuccess ||
+            blocks < 1 || cus < 1) {
+            (void)hipGetLastError();
+            return hipErrorInvalidValue;
+        }
+        resident = cus * blocks * kWavesPerBlock;
+    }
+    ChainArgs a;
+    a.n_steps = n_steps;
+    a.epoch = epoch;
+    a.flags = flags;
+    a.timed_out = timed_out;
+    int most = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const ChainStep &st = steps[i];
+        int rpc = rows_per_chunk > st.g_end - st.g_begin ? st.g_end - st.g_begin : rows_per_chunk;
+        if (rpc <= 0) rpc = auto_rows_per_chunk<B>(g, st.g_begin, st.g_end, NS, resident, device_simds());
+        sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, st.g_begin, st.g_end, rpc,
+                                         sor::kEdgeRowCost16, kFlipTiles ? 1 + (st.sweep & 1) : 0);
+        t.rotate = 0;
+        a.link[i].t = t;
+        a.link[i].hw = st.hw;
+        a.link[i].guard_flag = st.guard_flag;
+        a.link[i].guard_epoch = st.guard_epoch;
+        a.link[i].guard_lo_end = st.guard_lo_end;
+        a.link[i].guard_hi_begin = st.guard_hi_begin;
+        if (t.n_tiles > most) most = t.n_tiles;
+        if (senders) {
+            int n = 0;
+            if (st.hw.done)
+                for (int k = 0; k < t.n_tiles; ++k) {
+                    const sor::TileRect r = sor::tile_rect(t, k);
+                    n += r.r0 < st.hw.send_lo_end || r.r1 > st.hw.send_hi_begin;
+                }
+            senders[i] = n;
+        }
+    }
+    if (most == 0) return hipSuccess;
+    if ((long)most * SFL_CHAIN_FLAG_STRIDE > (long)flag_words) return hipErrorInvalidValue;
+    int waves = most;
+    if (waves > resident) waves = resident;
+    if (max_waves > 0 && waves > max_waves) waves = max_waves;
+    a.waves = waves;
+    const int blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    sor_chain_kernel<B, NS, DX1><<<blocks, kThreads, 0, s>>>(pa, pb, d, g, prm, a);
+    return hipGetLastError();
+}
+
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                      SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
@@ -756,6 +968,66 @@ SFL_DEFINE_NS(14)
 #endif
 #if SFL_NS_GROUP == 5 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(16)
+#endif
+
+// The chained launch: its kernels live in translation units of their own (SFL_NS_GROUP 6: fuse 8 and 10, 7: fuse 12 and 16).
+#define SFL_CHAIN_ARGS                                                                                                  \
+    hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps, SorParams prm,   \
+        int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out, int max_waves, int *senders
+#define SFL_DEFINE_CHAIN_PART(N, P, DX1)                                                                                \
+    hipError_t launch_sor_chain_ns##N##_p##P(SFL_CHAIN_ARGS)                                                            \
+    {                                                                                                                  \
+        return launch_chain_variant<Lane2<N, true, false, SFL_CHAIN_ST, SFL_CHAIN_LD>, N, DX1>(s, pa, pb, d, g, steps, n_steps, prm,        \
+                                                                           rows_per_chunk, flags, flag_words, epoch,   \
+                                                                           timed_out, max_waves, senders);             \
+    }
+#if SFL_DX_PART == 0
+#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 0, true)
+#elif SFL_DX_PART == 1
+#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 1, false)
+#else
+#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 0, true) SFL_DEFINE_CHAIN_PART(N, 1, false)
+#endif
+#define SFL_DECLARE_CHAIN(N)                                  \
+    hipError_t launch_sor_chain_ns##N##_p0(SFL_CHAIN_ARGS);   \
+    hipError_t launch_sor_chain_ns##N##_p1(SFL_CHAIN_ARGS);
+SFL_DECLARE_CHAIN(8) SFL_DECLARE_CHAIN(10) SFL_DECLARE_CHAIN(12) SFL_DECLARE_CHAIN(16)
+#if SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1
+SFL_DEFINE_CHAIN(8) SFL_DEFINE_CHAIN(10)
+#endif
+#if SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1
+SFL_DEFINE_CHAIN(12) SFL_DEFINE_CHAIN(16)
+#endif
+
+#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
+bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps)
+{
+    const uintptr_t all = reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(d);
+    return (nsweeps == 8 || nsweeps == 10 || nsweeps == 12 || nsweeps == 16) && g.dim_x % 2 == 0 && (all & 7) == 0 &&
+           pa != nullptr && pb != nullptr && pa != pb && d != nullptr;
+}
+
+hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
+                            int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch,
+                            int *timed_out, int max_waves, int *senders)
+{
+    if (n_steps < 1 || n_steps > kMaxChain || !sor_chain_supported(pa, pb, d, g, nsweeps) || flags == nullptr || timed_out == nullptr)
+        return hipErrorInvalidValue;
+    for (int i = 0; i < n_steps; ++i)
+        if (steps[i].g_end <= steps[i].g_begin) return hipErrorInvalidValue;
+    const bool dx1 = prm.dx == 1.0f;
+#define SFL_CASE(N)                                                                                                        \
+    case N:                                                                                                                \
+        return dx1 ? launch_sor_chain_ns##N##_p0(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
+                                                 epoch, timed_out, max_waves, senders)                                     \
+                   : launch_sor_chain_ns##N##_p1(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
+                                                 epoch, timed_out, max_waves, senders);
+    switch (nsweeps) {
+        SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(16)
+    }
+#undef SFL_CASE
+    return hipErrorInvalidValue;
+}
 #endif
 
 #if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1

@@ -124,6 +124,10 @@ extern "C" {
                                      subtract_gradient + dye advection of one and velocity advection + divergence of the
                                      next run as ONE kernel (the projected velocity in between is never written to memory);
                                      0 = n times sfl_step.  Same results either way                              */
+#define SFL_OPT_SOR_CHAIN 15       /* kernel 2: 1 = consecutive launches of a solve run as ONE chained launch whose waves go from
+                                     one superstep to the next without a launch boundary, each tile waiting only for the tiles
+                                     around it (fuse depths 8 / 10 / 12 / 16, even dim_x); 0 = one launch per superstep.
+                                     Same results either way                                                       */
 
 typedef struct sfl_context sfl_context;
 

@@ -1062,6 +1062,33 @@ def test_every_fuse_depth_from_zero_and_continuing(sfl, oracle, fuse):
         assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"fuse {fuse} dx {dx}")
 
 
+@pytest.mark.parametrize("fuse", [8, 10, 12, 16])
+@pytest.mark.parametrize("dim_x,dim_y,rows", [(1500, 1100, 0), (3000, 700, 23), (258, 2000, 0), (1030, 513, 40), (8192, 1024, 0)])
+def test_chained_launch_gives_the_same_bits(sfl, oracle, fuse, dim_x, dim_y, rows):
+    """SFL_OPT_SOR_CHAIN: the launches of a solve behind the first one as ONE launch whose waves go from superstep to
+    superstep, each tile waiting only for the tiles around it (sor_chain_kernel).  Against the oracle on shapes with many
+    tiles per strip and per wave, pitches that are not whole cache lines, forced and automatic tile heights, dx = 1 and
+    dx != 1, up to seven supersteps per chain -- and the chained launch really ran."""
+    if dim_x * dim_y > 4_000_000 and fuse not in (10, 16):
+        pytest.skip("the thin share of the headline grid: the two depths it is run at")
+    _, _, d = random_fields(dim_x, dim_y, 90 + fuse)
+    for dx, launches in ((1.0, 7), (0.75, 4)):
+        iters = fuse // 2 * launches
+        with sfl.Solver(dim_x, dim_y) as s:
+            s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
+            s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+            s.set_option(sfl.capi.OPT_SOR_ROWS, rows)
+            s.set_option(sfl.capi.OPT_SOR_CHAIN, 1)
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+            for _ in range(2):          # twice: the words of the first chain are still there for the second
+                s.poisson_solve(dx, iters, OMEGA)
+            s.synchronize()
+            info = s.last_solve_info()
+            got = s.download(sfl.capi.FIELD_PRESSURE)
+        assert info["fuse"] == fuse and info["launches"] == launches
+        assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"chained, fuse {fuse} dx {dx} {dim_x}x{dim_y}")
+
+
 SMALL_SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (80, 60), (64, 48), (127, 33), (128, 48), (78, 78),
                 (3, 2048), (2047, 3), (2, 3072), (3072, 2), (257, 23), (128, 80), (101, 101)]
 
