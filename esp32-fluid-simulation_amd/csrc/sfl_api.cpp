@@ -269,7 +269,14 @@ int min_owned_rows(const sfl_context *c)
 // `on` = stream to issue the transfers on (nullptr: the contexts' compute stream).
 // `skip` > 0: only the rows at depth [skip, skip + rows) from the cuts travel (the ghost rows nearer the cut
 // are still valid: early exchanges of slab_plan.cpp).
-int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipStream_t on = nullptr, int skip = 0)
+// `in_time` (run_poisson_in_time): the exchange is one step of the device-counted protocol -- it starts when the sender tiles
+// of the launch in front of it have counted themselves (`wait_done`; the right-hand side's exchange starts behind an event
+// instead) and ends by raising every receiver's arrival count, with a kernel behind the message's own.  (Raising it in the
+// copy kernel itself -- written-through stores, the block that finishes last stores the word -- saves that kernel, 4 - 6 us,
+// beside the solve's first launch, which only reads d, and costs more than it saves beside a launch at full memory traffic:
+// the copy's stores then take 10 us to drain.  Measured, not kept: profiles/r04_exchanges_counted_on_the_device.txt.)
+int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipStream_t on = nullptr, int skip = 0,
+             bool in_time = false, bool wait_done = false)
 {
     if (rows <= 0) return SFL_OK;
     sfl_context *any = peers[0];
@@ -293,14 +300,22 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
     };
 
     if (any->group) {  // in-process transport: all virtual ranks share one stream
+        if (in_time && wait_done)   // every slab's sender tiles first (a slab reads from its two neighbours)
+            for (sfl_context *c : peers) {
+                SFL_TRY(use_device(c));
+                HIP_TRY(sfl::launch_wait_count(on ? on : c->stream, c->d_done, c->done_target, c->d_arrival + 1));
+            }
         for (sfl_context *c : peers) {   // both bands of a slab in one launch
             SFL_TRY(use_device(c));
             sfl_context *lo = c->rank > 0 ? peers[c->rank - 1] : nullptr;
             sfl_context *hi = c->rank < c->nranks - 1 ? peers[c->rank + 1] : nullptr;
-            HIP_TRY(sfl::launch_copy_bands(on ? on : c->stream, lo ? row_ptr(c, c->g0 - skip - rows) : nullptr,
-                                           lo ? row_ptr(lo, lo->g1 - skip - rows) : nullptr,
-                                           hi ? row_ptr(c, c->g1 + skip) : nullptr, hi ? row_ptr(hi, hi->g0 + skip) : nullptr,
-                                           bytes));
+            void *dst_a = lo ? row_ptr(c, c->g0 - skip - rows) : nullptr, *dst_b = hi ? row_ptr(c, c->g1 + skip) : nullptr;
+            const void *src_a = lo ? row_ptr(lo, lo->g1 - skip - rows) : nullptr, *src_b = hi ? row_ptr(hi, hi->g0 + skip) : nullptr;
+            HIP_TRY(sfl::launch_copy_bands(on ? on : c->stream, dst_a, src_a, dst_b, src_b, bytes));
+            if (in_time) {
+                ++c->arrival_epoch;
+                HIP_TRY(sfl::launch_signal_arrival(on ? on : c->stream, c->d_arrival, c->arrival_epoch));
+            }
         }
         return SFL_OK;
     }
@@ -312,11 +327,16 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         // so results next to the cuts mean nothing; launches, copies and their ordering are the rank's program.
         SFL_TRY(use_device(c));
         hipStream_t st = on ? on : c->stream;
-        HIP_TRY(sfl::launch_spin_us(st, c->opt_emulate_wire_us));   // the wire a self-copy does not have (0: none)
         const bool lo = c->rank > 0, hi = c->rank < c->nranks - 1;
-        HIP_TRY(sfl::launch_copy_bands(st, lo ? row_ptr(c, c->g0 - skip - rows) : nullptr, lo ? row_ptr(c, c->g0 + skip) : nullptr,
-                                       hi ? row_ptr(c, c->g1 + skip) : nullptr, hi ? row_ptr(c, c->g1 - skip - rows) : nullptr,
-                                       bytes));
+        void *dst_a = lo ? row_ptr(c, c->g0 - skip - rows) : nullptr, *dst_b = hi ? row_ptr(c, c->g1 + skip) : nullptr;
+        const void *src_a = lo ? row_ptr(c, c->g0 + skip) : nullptr, *src_b = hi ? row_ptr(c, c->g1 - skip - rows) : nullptr;
+        if (in_time && wait_done) HIP_TRY(sfl::launch_wait_count(st, c->d_done, c->done_target, c->d_arrival + 1));
+        HIP_TRY(sfl::launch_spin_us(st, c->opt_emulate_wire_us));   // the wire a self-copy does not have (0: none)
+        HIP_TRY(sfl::launch_copy_bands(st, dst_a, src_a, dst_b, src_b, bytes));
+        if (in_time) {
+            ++c->arrival_epoch;
+            HIP_TRY(sfl::launch_signal_arrival(st, c->d_arrival, c->arrival_epoch));
+        }
         return SFL_OK;
     }
     if (!c->comm)
@@ -324,6 +344,7 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
                     "sfl_group_link() first", c->rank, c->nranks);
     SFL_TRY(use_device(c));
     hipStream_t st = on ? on : c->stream;
+    if (in_time && wait_done) HIP_TRY(sfl::launch_wait_count(st, c->d_done, c->done_target, c->d_arrival + 1));
     NCCL_TRY(ncclGroupStart());
     if (c->rank > 0) {
         NCCL_TRY(ncclSend(row_ptr(c, c->g0 + skip), bytes, ncclChar, c->rank - 1, c->comm, st));
@@ -334,6 +355,10 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         NCCL_TRY(ncclRecv(row_ptr(c, c->g1 + skip), bytes, ncclChar, c->rank + 1, c->comm, st));
     }
     NCCL_TRY(ncclGroupEnd());
+    if (in_time) {
+        ++c->arrival_epoch;
+        HIP_TRY(sfl::launch_signal_arrival(st, c->d_arrival, c->arrival_epoch));
+    }
     return SFL_OK;
 }
 
@@ -427,16 +452,6 @@ int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParam
 // Device-side halo arrival (run_poisson_in_time, kernels.h HaloWait).  The exchange stream counts a context's arrived
 // messages in a device word; the next launch on the compute stream is queued WITHOUT a cross-stream event and lets only
 // its cut-adjacent tiles wait for the count.
-int signal_arrival(const std::vector<sfl_context *> &peers, hipStream_t xstream)
-{
-    for (sfl_context *c : peers) {
-        SFL_TRY(use_device(c));
-        ++c->arrival_epoch;
-        HIP_TRY(sfl::launch_signal_arrival(xstream, c->d_arrival, c->arrival_epoch));
-    }
-    return SFL_OK;
-}
-
 sfl::HaloWait arrival_wait(const sfl_context *c)
 {
     sfl::HaloWait w;
@@ -554,12 +569,12 @@ int overlap_of(sfl_context *c, Overlap *o)
 // `mark` = false: the caller queues more work behind the exchange on the exchange stream and records
 // `arrived` itself (mark_arrived).
 int start_exchange(const std::vector<sfl_context *> &peers, const Overlap &o, int field, int rows, int skip = 0,
-                   bool mark = true)
+                   bool mark = true, bool in_time = false)
 {
     SFL_TRY(use_device(peers[0]));
     HIP_TRY(hipEventRecord(o.ready, o.compute));
     HIP_TRY(hipStreamWaitEvent(o.xstream, o.ready, 0));
-    SFL_TRY(exchange(peers, field, rows, o.xstream, skip));
+    SFL_TRY(exchange(peers, field, rows, o.xstream, skip, in_time));
     SFL_TRY(use_device(peers[0]));
     if (mark) HIP_TRY(hipEventRecord(o.arrived, o.xstream));
     return SFL_OK;
@@ -673,9 +688,7 @@ int chain_in_time(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t
         c->done_target += senders[q];
         if (xch[q] < 0) continue;
         const sfl_plan_step &x = prog[xch[q]];
-        HIP_TRY(sfl::launch_wait_count(o.xstream, c->d_done, c->done_target, c->d_arrival + 1));
-        SFL_TRY(exchange(self, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin));
-        SFL_TRY(signal_arrival(self, o.xstream));
+        SFL_TRY(exchange(self, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
     }
     *flagged = fl;
     *band = b;
@@ -699,8 +712,7 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
         if (st0.kind == SFL_STEP_EXCHANGE) {   // the right-hand side (a p exchange is taken together with the launch before it)
-            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false));
-            SFL_TRY(signal_arrival(peers, o.xstream));
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false, true));
             flagged = true;
             continue;
         }
@@ -735,12 +747,7 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
         flagged = false;
         if (sends) {
             const sfl_plan_step &x = progs[0][i + 1];
-            for (sfl_context *c : peers) {
-                SFL_TRY(use_device(c));
-                HIP_TRY(sfl::launch_wait_count(o.xstream, c->d_done, c->done_target, c->d_arrival + 1));
-            }
-            SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin));
-            SFL_TRY(signal_arrival(peers, o.xstream));
+            SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
             flagged = true;
             band.valid = true;
             band.epoch = ctx->arrival_epoch;
