@@ -286,9 +286,10 @@ def parse_args(argv=None):
                     help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
     ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
-    ap.add_argument("--chain", type=int, default=None, choices=(0, 1),
+    ap.add_argument("--chain", type=int, default=None, choices=(-1, 0, 1),
                     help="SFL_OPT_SOR_CHAIN: 1 = the launches of a solve as chained launches (waves go from one superstep to the "
-                         "next, tiles wait for the tiles around them), 0 = one launch per superstep; default: the library's")
+                         "next, tiles wait for the tiles around them), 0 = one launch per superstep, -1 = automatic (thin slabs "
+                         "with a transport); default: the library's (0)")
     ap.add_argument("--arrival-by-event", action="store_true",
                     help="SFL_OPT_SOR_ARRIVAL = 0: early halo exchanges behind cross-stream events (round 3's scheme) instead of "
                          "in-time exchanges counted on the device (A/B)")
@@ -506,6 +507,7 @@ def run_rank(args):
             s.poisson_solve(1.0, iters, omega)
     elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
+    info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
 
     # ---- parity of the timed configuration: the p the last timed solve left behind is downloaded
     # NOW (with the right-hand side it was solved for); the reference CPU loop runs after all GPU
@@ -620,6 +622,7 @@ def run_rank(args):
             (cells * iters / unprimed * 1e3) if unprimed else None,
             "cell_iters_per_sec_of_this_rank": cells * iters * args.steps / elapsed,
             "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
+            "supersteps_in_chained_launches": info["chained"],
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
             "emulated_wire_us": args.wire_us,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None, **({"sim_steps_note": sim_note} if sim_note else {}),
@@ -703,6 +706,7 @@ def run_rank(args):
                        "grid": [size, dim_y], "iters": iters,
                        "parallelism": "1 GPU" if world == 1 else f"row-slab x{world}, RCCL halo exchange",
                        "sor_launches_per_solve": info["launches"],
+                       "supersteps_in_chained_launches": info["chained"],
                        "halo_exchanges_per_solve": info["exchanges"],
                        "half_sweeps_fused_per_launch": info["fuse"]},
             "parity": parity,

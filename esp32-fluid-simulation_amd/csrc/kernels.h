@@ -168,9 +168,11 @@ struct ChainStep {
     int guard_epoch, guard_lo_end, guard_hi_begin;
 };
 bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps);
+// `tiles_at_most` > 0: launch only if no superstep has more tiles than that (the chain pays where every tile is resident at two
+// waves per SIMD: thin slabs), *launched says which; 0: always.
 hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
                             int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch,
-                            int *timed_out, int max_waves, int *senders);
+                            int *timed_out, int max_waves, int *senders, int tiles_at_most = 0, bool *launched = nullptr);
 // *flag = value, visible to every CU (stream-ordered behind the message / the kernels that relaxed it)
 hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value);
 // One wave that returns when *count has reached `target` (signed distance; sender tiles of launches on ANOTHER stream

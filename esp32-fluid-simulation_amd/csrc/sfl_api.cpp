@@ -163,7 +163,7 @@ struct sfl_context {
     std::shared_ptr<Group> group;       // collective membership (in-process virtual ranks)
     std::shared_ptr<Group> keepalive;   // keeps the group's shared stream alive
 
-    int last_launches = 0, last_exchanges = 0, last_fuse = 0;
+    int last_launches = 0, last_exchanges = 0, last_fuse = 0, last_chained = 0;
     int solve_tail = 0;   // ghost rows of p the next solve must leave exact (slab_step_auto: 1, for subtract_gradient)
     int p_ghost_valid = 0;  // ghost rows of p that are exact right now (set by the solve, cleared by whoever writes p)
     int v_ghost_valid = 0;  // ghost rows of the velocity that are exact right now (slab_step_auto advects own +- 1 rows)
@@ -180,8 +180,18 @@ struct Group {
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // in-process halo copies of a solve (see sfl_context::xstream)
     hipEvent_t ev_ready = nullptr, ev_arrived = nullptr;
+    // chained launches (SFL_OPT_SOR_CHAIN) of virtual ranks run side by side: the first on `stream`, the others here.  Created
+    // right behind `xstream`: the runtime deals streams to its hardware queues in turn, and these streams, `stream` and `xstream`
+    // must not share one (a chain that waits for a message would sit in front of the copy that carries it)
+    static constexpr int kSideChains = 2;
+    hipStream_t chain_stream[kSideChains] = {nullptr, nullptr};
+    hipEvent_t ev_chain[kSideChains] = {nullptr, nullptr};
     ~Group()
     {
+        for (int k = 0; k < kSideChains; ++k) {
+            if (ev_chain[k]) (void)hipEventDestroy(ev_chain[k]);
+            if (chain_stream[k]) (void)hipStreamDestroy(chain_stream[k]);
+        }
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_arrived) (void)hipEventDestroy(ev_arrived);
         if (xstream) (void)hipStreamDestroy(xstream);
@@ -312,11 +322,15 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
             void *dst_a = lo ? row_ptr(c, c->g0 - skip - rows) : nullptr, *dst_b = hi ? row_ptr(c, c->g1 + skip) : nullptr;
             const void *src_a = lo ? row_ptr(lo, lo->g1 - skip - rows) : nullptr, *src_b = hi ? row_ptr(hi, hi->g0 + skip) : nullptr;
             HIP_TRY(sfl::launch_copy_bands(on ? on : c->stream, dst_a, src_a, dst_b, src_b, bytes));
-            if (in_time) {
+        }
+        // every copy before any signal: a slab's arrival count then also says that its neighbours have READ what it sent
+        // (the chained launch's guard, kernels.h ChainStep::guard_flag, relies on that)
+        if (in_time)
+            for (sfl_context *c : peers) {
+                SFL_TRY(use_device(c));
                 ++c->arrival_epoch;
                 HIP_TRY(sfl::launch_signal_arrival(on ? on : c->stream, c->d_arrival, c->arrival_epoch));
             }
-        }
         return SFL_OK;
     }
 
@@ -490,7 +504,7 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
 // May plan steps [i, i + n) of `prog` go into one chained launch?  SOR steps of one supported fuse depth, none from zero.
 int chainable_steps(const sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, bool across_exchanges)
 {
-    if (!c->opt_sor_chain || effective_kernel(c) != 2) return 0;
+    if (c->opt_sor_chain <= 0 || effective_kernel(c) != 2) return 0;   // (automatic: only where exchanges run in time, below)
     int n = 0;
     size_t k = i;
     for (; k < prog.size() && n < sfl::kMaxChain; ++k) {
@@ -534,10 +548,12 @@ int exec_sor_chain(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_
         steps[k].guard_epoch = steps[k].guard_lo_end = steps[k].guard_hi_begin = 0;
     }
     HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, prog[i].nsweeps, prm, c->opt_sor_rows,
-                                  c->d_chain, c->chain_words, c->chain_epoch, c->d_arrival + 1, 0, nullptr));
+                                  c->d_chain, c->chain_words, c->chain_epoch, c->d_arrival + 1,
+                                  c->opt_sor_chain >= 8 ? c->opt_sor_chain & ~3 : 0, nullptr));
     c->chain_epoch += n + 1;
     if (n & 1) std::swap(c->p, c->p_alt);
     c->last_launches += n;
+    c->last_chained += n;
     return SFL_OK;
 }
 
@@ -554,7 +570,14 @@ int overlap_of(sfl_context *c, Overlap *o)
     hipStream_t *xs = c->group ? &c->group->xstream : &c->xstream;
     hipEvent_t *e0 = c->group ? &c->group->ev_ready : &c->ev_ready;
     hipEvent_t *e1 = c->group ? &c->group->ev_arrived : &c->ev_arrived;
-    if (!*xs) HIP_TRY(hipStreamCreateWithFlags(xs, hipStreamNonBlocking));
+    if (!*xs) {
+        HIP_TRY(hipStreamCreateWithFlags(xs, hipStreamNonBlocking));
+        if (c->group)
+            for (int k = 0; k < Group::kSideChains; ++k) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->group->chain_stream[k], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->group->ev_chain[k], hipEventDisableTiming));
+            }
+    }
     if (!*e0) HIP_TRY(hipEventCreateWithFlags(e0, hipEventDisableTiming));
     if (!*e1) HIP_TRY(hipEventCreateWithFlags(e1, hipEventDisableTiming));
     o->compute = c->stream;  // a linked group shares one compute stream
@@ -614,23 +637,28 @@ struct SentBand {
     int epoch = 0, lo_end = 0, hi_begin = 0, age = 0;
 };
 
-// In-time exchanges with the launches CHAINED (SFL_OPT_SOR_CHAIN): the SOR steps from prog[i] on -- up to kMaxChain, p exchanges
-// between and behind them included -- as one chained launch on the compute stream, with the exchange stream's work (wait for
-// the sender count, copy / send, raise the arrival count) queued behind it exactly as for single launches.  One context only:
-// the chains of several virtual ranks on one stream would wait for each other's messages in vain.  *next = first plan step not
-// consumed (== i: nothing was chained).
-int chain_in_time(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, const sfl::SorParams &prm, const Overlap &o,
-                  bool *flagged, SentBand *band, size_t *next)
+// In-time exchanges with the launches CHAINED (SFL_OPT_SOR_CHAIN): the SOR steps from step i on -- up to kMaxChain, p exchanges
+// between and behind them included -- as one chained launch per context, with the exchange stream's work (wait for the sender
+// counts, copy / send, raise the arrival counts) queued behind them exactly as for single launches.  The chains of the virtual
+// ranks of a group wait for each other's messages, so they must RUN side by side: the first on the compute stream, the others
+// on a stream of their own each (joined back into the compute stream), all of them within a budget of waves that is resident
+// at once.  *next = first plan step not consumed (== i: nothing was chained).
+int chain_in_time(const std::vector<sfl_context *> &peers, const std::vector<std::vector<sfl_plan_step>> &progs, size_t i,
+                  const sfl::SorParams &prm, const Overlap &o, bool *flagged, std::vector<SentBand> *bands, size_t *next)
 {
     *next = i;
-    const std::vector<sfl_context *> self{c};
+    const std::vector<sfl_plan_step> &prog = progs[0];   // every rank's program has the same shape
     std::vector<size_t> sor;
     std::vector<long> xch;   // the p exchange behind sor[k] (index into prog), or -1
     size_t k = i;
     const int ns = prog[i].nsweeps;
     while (k < prog.size() && (int)sor.size() < sfl::kMaxChain) {
-        const sfl_plan_step &st = prog[k];
-        if (st.kind != SFL_STEP_SOR || st.from_zero || st.first_colour != 0 || st.nsweeps != ns || st.g_end <= st.g_begin) break;
+        bool ok = true;
+        for (size_t r = 0; r < peers.size(); ++r) {
+            const sfl_plan_step &st = progs[r][k];
+            ok = ok && st.kind == SFL_STEP_SOR && !st.from_zero && st.first_colour == 0 && st.nsweeps == ns && st.g_end > st.g_begin;
+        }
+        if (!ok) break;
         sor.push_back(k++);
         if (k < prog.size() && prog[k].kind == SFL_STEP_EXCHANGE && prog[k].field == SFL_FIELD_PRESSURE)
             xch.push_back((long)k++);
@@ -638,60 +666,93 @@ int chain_in_time(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t
             xch.push_back(-1);
     }
     const int n = (int)sor.size();
-    if (n < 2 || !sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, ns)) return SFL_OK;
-    SFL_TRY(ensure_chain_words(c));
-    sfl::ChainStep steps[sfl::kMaxChain];
-    int epoch = c->arrival_epoch;   // the value the arrival count reaches with the exchanges issued so far
-    bool fl = *flagged;
-    SentBand b = *band;
-    for (int q = 0; q < n; ++q) {
-        const sfl_plan_step &st = prog[sor[q]];
-        sfl::ChainStep &cs = steps[q];
-        cs.g_begin = st.g_begin;
-        cs.g_end = st.g_end;
-        cs.sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + q : 0;
-        cs.hw = arrival_wait(c);
-        cs.hw.epoch = epoch;
-        if (!fl) cs.hw.flag = nullptr;
-        ++b.age;
-        cs.guard_flag = b.valid && b.age == 2 ? c->d_arrival : nullptr;
-        cs.guard_epoch = b.epoch;
-        cs.guard_lo_end = b.lo_end;
-        cs.guard_hi_begin = b.hi_begin;
-        fl = false;
-        if (xch[q] >= 0) {
-            const sfl_plan_step &x = prog[xch[q]];
-            cs.hw.done = c->d_done;
-            cs.hw.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
-            cs.hw.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
-            ++epoch;
-            fl = true;
-            b.valid = true;
-            b.epoch = epoch;
-            b.lo_end = cs.hw.send_lo_end;
-            b.hi_begin = cs.hw.send_hi_begin;
-            b.age = 0;
-        }
-    }
-    int senders[sfl::kMaxChain] = {0};
-    // room for the exchange stream's kernels beside the chain: two waves per SIMD at most
+    if (n < 2) return SFL_OK;
+    for (sfl_context *c : peers)
+        if (!sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, ns)) return SFL_OK;
+    // two waves per SIMD for all chains together: room for the exchange stream's kernels beside them, and the occupancy the
+    // chain runs best at -- a thin slab's tiling has two tiles per SIMD; the slabs that touch the domain's boundary have three,
+    // and their chains do better with two waves per SIMD that take a second tile (0.398 ms) than with three (0.444)
     int dev = 0, cus = 256;
+    SFL_TRY(use_device(peers[0]));
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    SFL_TRY(use_device(c));
-    HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, ns, prm, c->opt_sor_rows, c->d_chain,
-                                  c->chain_words, c->chain_epoch, c->d_arrival + 1, cus * 8, senders));
-    c->chain_epoch += n + 1;
-    if (n & 1) std::swap(c->p, c->p_alt);
-    c->last_launches += n;
+    int budget = cus * 8 / (int)peers.size();
+    if (peers[0]->opt_sor_chain >= 8 && peers[0]->opt_sor_chain < budget) budget = peers[0]->opt_sor_chain;
+    budget -= budget % 4;
+    // Side by side means a hardware queue each, for the compute stream, the exchange stream and every side stream; the runtime
+    // folds its streams onto GPU_MAX_HW_QUEUES (default 4) of them in turn.  Two virtual ranks fit the default; three when the
+    // process was started with more queues (tests/conftest.py does).  Folded streams are not a hang but a reported time-out.
+    static const int side_chains = [] {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        return q && atoi(q) >= 6 ? Group::kSideChains : 1;
+    }();
+    if (budget < 8 || (int)peers.size() > 1 + side_chains || (peers.size() > 1 && !peers[0]->group)) return SFL_OK;
+    for (sfl_context *c : peers) SFL_TRY(ensure_chain_words(c));   // (zeroed on the compute stream: before the event below)
+    if (peers.size() > 1) HIP_TRY(hipEventRecord(o.ready, o.compute));   // the side streams start behind what is queued so far
+
+    std::vector<std::vector<int>> senders(peers.size(), std::vector<int>(sfl::kMaxChain, 0));
+    bool fl_out = *flagged;
+    for (size_t r = 0; r < peers.size(); ++r) {
+        sfl_context *c = peers[r];
+        sfl::ChainStep steps[sfl::kMaxChain];
+        int epoch = c->arrival_epoch;   // the value the arrival count reaches with the exchanges issued so far
+        bool fl = *flagged;
+        SentBand b = (*bands)[r];
+        for (int q = 0; q < n; ++q) {
+            const sfl_plan_step &st = progs[r][sor[q]];
+            sfl::ChainStep &cs = steps[q];
+            cs.g_begin = st.g_begin;
+            cs.g_end = st.g_end;
+            cs.sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + q : 0;
+            cs.hw = arrival_wait(c);
+            cs.hw.epoch = epoch;
+            if (!fl) cs.hw.flag = nullptr;
+            ++b.age;
+            cs.guard_flag = b.valid && b.age == 2 ? c->d_arrival : nullptr;
+            cs.guard_epoch = b.epoch;
+            cs.guard_lo_end = b.lo_end;
+            cs.guard_hi_begin = b.hi_begin;
+            fl = false;
+            if (xch[q] >= 0) {
+                const sfl_plan_step &x = progs[r][xch[q]];
+                cs.hw.done = c->d_done;
+                cs.hw.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                cs.hw.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+                ++epoch;
+                fl = true;
+                b.valid = true;
+                b.epoch = epoch;
+                b.lo_end = cs.hw.send_lo_end;
+                b.hi_begin = cs.hw.send_hi_begin;
+                b.age = 0;
+            }
+        }
+        hipStream_t on = c->stream;
+        if (r > 0) {
+            on = c->group->chain_stream[r - 1];
+            HIP_TRY(hipStreamWaitEvent(on, o.ready, 0));
+        }
+        bool launched = false;
+        HIP_TRY(sfl::launch_sor_chain(on, c->p, c->p_alt, c->div, c->geom, steps, n, ns, prm, c->opt_sor_rows, c->d_chain,
+                                      c->chain_words, c->chain_epoch, c->d_arrival + 1, budget, senders[r].data(),
+                                      c->opt_sor_chain < 0 ? cus * 13 : 0, &launched));
+        if (!launched) return SFL_OK;   // (automatic mode: thin slabs only; first context: nothing has been changed yet)
+        if (r > 0) HIP_TRY(hipEventRecord(c->group->ev_chain[r - 1], on));
+        c->chain_epoch += n + 1;
+        c->last_launches += n;
+        c->last_chained += n;
+        (*bands)[r] = b;
+        fl_out = fl;
+    }
+    for (size_t r = 1; r < peers.size(); ++r) HIP_TRY(hipStreamWaitEvent(o.compute, peers[r]->group->ev_chain[r - 1], 0));
     for (int q = 0; q < n; ++q) {
-        c->done_target += senders[q];
+        for (sfl_context *c : peers) std::swap(c->p, c->p_alt);   // c->p = what superstep q writes: the message's source
+        for (size_t r = 0; r < peers.size(); ++r) peers[r]->done_target += senders[r][q];
         if (xch[q] < 0) continue;
         const sfl_plan_step &x = prog[xch[q]];
-        SFL_TRY(exchange(self, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
+        SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
     }
-    *flagged = fl;
-    *band = b;
+    *flagged = fl_out;
     *next = k;
     return SFL_OK;
 }
@@ -707,7 +768,8 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
                         const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
 {
     bool flagged = false;   // the next launch's cut-adjacent tiles wait for the arrival count
-    SentBand band;          // the last p message's source rows (chained launches)
+    std::vector<SentBand> bands(peers.size());   // the last p message's source rows, per context (chained launches)
+    bool chain_refused = false;
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -716,15 +778,18 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             flagged = true;
             continue;
         }
-        if (peers.size() == 1 && ctx->opt_sor_chain && !st0.from_zero) {
+        // automatic (-1): a context with a transport of its own (RCCL, the emulated rank) on slabs thin enough that every tile is
+        // resident at two waves per SIMD; virtual ranks (a test transport) only when asked to
+        if ((ctx->opt_sor_chain > 0 || (ctx->opt_sor_chain < 0 && !ctx->group && !chain_refused)) && !st0.from_zero) {
             size_t next = i;
-            SFL_TRY(chain_in_time(ctx, progs[0], i, prm, o, &flagged, &band, &next));
+            SFL_TRY(chain_in_time(peers, progs, i, prm, o, &flagged, &bands, &next));
             if (next > i) {
                 i = next - 1;
                 continue;
             }
+            chain_refused = true;   // decided once per solve: the first attempt holds the widest row ranges
         }
-        ++band.age;
+        for (SentBand &b : bands) ++b.age;
         const bool sends = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE && progs[0][i + 1].field == SFL_FIELD_PRESSURE;
         for (size_t k = 0; k < peers.size(); ++k) {
             sfl_context *c = peers[k];
@@ -749,11 +814,14 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             const sfl_plan_step &x = progs[0][i + 1];
             SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
             flagged = true;
-            band.valid = true;
-            band.epoch = ctx->arrival_epoch;
-            band.lo_end = ctx->rank > 0 ? ctx->g0 + x.g_begin + x.rows : -(1 << 30);
-            band.hi_begin = ctx->rank < ctx->nranks - 1 ? ctx->g1 - x.g_begin - x.rows : (1 << 30);
-            band.age = 0;
+            for (size_t k = 0; k < peers.size(); ++k) {
+                const sfl_context *c = peers[k];
+                bands[k].valid = true;
+                bands[k].epoch = c->arrival_epoch;
+                bands[k].lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                bands[k].hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+                bands[k].age = 0;
+            }
             ++i;   // the exchange step has been issued
         }
     }
@@ -922,7 +990,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse,
                                           kernel == 2 && in_time_exchanges(ctx) ? 3 : kernel, effective_halo(ctx, fuse),
                                           ctx->solve_tail));
-        c->last_launches = c->last_exchanges = 0;
+        c->last_launches = c->last_exchanges = c->last_chained = 0;
         c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
@@ -1285,6 +1353,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             return SFL_OK;
         case SFL_OPT_TRANSPORT:
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
+        case SFL_OPT_LAST_CHAINED:
+            return fail(SFL_ERR_INVALID, "SFL_OPT_LAST_CHAINED is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
@@ -1312,7 +1382,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_step_seams = value ? 1 : 0;
             return SFL_OK;
         case SFL_OPT_SOR_CHAIN:
-            c->opt_sor_chain = value ? 1 : 0;
+            if (value < -1) return fail(SFL_ERR_INVALID, "SFL_OPT_SOR_CHAIN must be -1 (auto), 0, 1 or a number of waves >= 8");
+            c->opt_sor_chain = value;   // >= 8: on, with at most that many waves per chain (several tiles per wave: a test aid)
             return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
@@ -1364,6 +1435,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_ARRIVAL: *value = c->opt_sor_arrival; return SFL_OK;
         case SFL_OPT_STEP_SEAMS: *value = c->opt_step_seams; return SFL_OK;
         case SFL_OPT_SOR_CHAIN: *value = c->opt_sor_chain; return SFL_OK;
+        case SFL_OPT_LAST_CHAINED: *value = c->last_chained; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -1395,7 +1467,7 @@ static void option_block(const sfl_context *c, int *b)
 {
     const int v[kOptionBlockInts] = {SFL_ABI_VERSION, c->dim_x, c->gdim_y, c->nranks, c->opt_sor_kernel, c->opt_sor_fuse,
                                      c->opt_sor_halo, c->opt_sor_overlap, c->opt_advect_halo, c->opt_fuse_projection,
-                                     c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, c->opt_sor_arrival, 0, 0};
+                                     c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, c->opt_sor_arrival, c->opt_sor_chain, 0};
     memcpy(b, v, sizeof v);
 }
 
@@ -1523,6 +1595,7 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_fuse_divergence = z->opt_fuse_divergence;
         c->opt_small_grid = z->opt_small_grid;
         c->opt_sor_arrival = z->opt_sor_arrival;
+        c->opt_sor_chain = z->opt_sor_chain;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
@@ -2381,7 +2454,7 @@ int sfl_synchronize(sfl_context *ctx)
     for (sfl_context *c : peers_of(ctx)) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->nranks > 1) {
+        if (c->nranks > 1 || c->d_chain) {
             int words[3] = {0, 0, 0};   // halo_flag, arrival count, a wait for it timed out
             HIP_TRY(hipMemcpy(words, c->halo_flag, sizeof words, hipMemcpyDeviceToHost));
             if (words[0]) {
@@ -2391,9 +2464,11 @@ int sfl_synchronize(sfl_context *ctx)
             }
             if (words[2]) {
                 HIP_TRY(hipMemset(c->halo_flag + 2, 0, sizeof(int)));
-                rc = fail(SFL_ERR_HIP, "slab %d/%d: tiles of a solve waited longer than %d s for a halo message (arrival "
+                // bits: 1 a tile of a launch, 4 a tile of a chained launch, 8 the exchange stream (for the sender count) waited
+                // for a halo message; 2 a tile of a chained launch for the tiles around it
+                rc = fail(SFL_ERR_HIP, "slab %d/%d: a wait inside a solve lasted longer than %d s (waits 0x%x; arrival "
                           "count %d of %d): the pressure field is not valid", c->rank, c->nranks,
-                          sfl::kHaloWaitTimeoutUs / 1000000, words[1], c->arrival_epoch);
+                          sfl::kHaloWaitTimeoutUs / 1000000, words[2], words[1], c->arrival_epoch);
             }
         }
     }

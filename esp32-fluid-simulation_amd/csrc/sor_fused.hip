@@ -9,6 +9,9 @@
 // gfx950 -- profiles/r02_experiments_without_gain.txt -- it was never faster and is gone.)
 //
 // Compiled with -ffp-contract=off (bit-exactness contract, see stencil_kernels.hip).
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 #include "sor_stream_core.h"
 
@@ -681,11 +684,11 @@ sor_chain_kernel(float *pa, float *pb, const float *d, Slab g, SorParams prm, Ch
         for (int tile = slot; tile < t.n_tiles; tile += a.waves) {
             const sor::TileRect rect = sor::tile_rect(t, tile);
             const int r0 = rect.r0, r1 = rect.r1;
-            bool ok = true;
+            int late = 0;   // which wait gave up (bits of *timed_out: 2 = for the tiles around, 4 = for a halo message)
             // the previous superstep's tiles around this one: their output is this tile's input, and this tile's output
             // replaces their input (the two arrays take turns)
             if (s > 0 && !SFL_PROBE_CHAIN_NO_DEPS)
-                ok = chain_wait(a.link[s - 1].t, rect.strip, r0 - reach, r1 + reach, a.flags, a.epoch + s, lane);
+                late = chain_wait(a.link[s - 1].t, rect.strip, r0 - reach, r1 + reach, a.flags, a.epoch + s, lane) ? 0 : 2;
             // the halo message of the exchange in front of this superstep (see sor_fused_kernel; no acquire: sc1 loads), and
             // the message two supersteps back whose source this tile overwrites (kernels.h ChainStep::guard_flag)
             const bool incoming = hw.flag != nullptr && (r0 - reach < hw.own_lo || r1 + reach > hw.own_hi);
@@ -697,12 +700,12 @@ sor_chain_kernel(float *pa, float *pb, const float *d, Slab g, SorParams prm, Ch
                 while ((int)((unsigned)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) < 0) {
                     __builtin_amdgcn_s_sleep(20);
                     if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
-                        ok = false;
+                        late |= 4;
                         break;
                     }
                 }
             }
-            if (!ok && lane == 0) atomicOr(a.timed_out, 1);
+            if (late && lane == 0) atomicOr(a.timed_out, late);
             const bool sender = hw.done != nullptr && (r0 < hw.send_lo_end || r1 > hw.send_hi_begin);
             relax_tile<B, NS, DX1, false>(p_out, p_in, d, g, t, rect, prm, sender, ring_mem[wave], lane);
             // publish: the rows are written through; once this wave's stores have left, the word may say so
@@ -826,8 +829,9 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
 template <class B, int NS, bool DX1>
 hipError_t launch_chain_variant(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
                                 SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out,
-                                int max_waves, int *senders)
+                                int max_waves, int *senders, int tiles_at_most, bool *launched)
 {
+    if (launched) *launched = false;
     static int resident = 0;   // waves of this kernel the device holds at once
     if (!resident) {
         int dev = 0, cus = 0, blocks = 0;
@@ -869,8 +873,12 @@ hipError_t launch_chain_variant(hipStream_t s, float *pa, float *pb, const float
             senders[i] = n;
         }
     }
-    if (most == 0) return hipSuccess;
+    if (getenv("SFL_DEBUG_CHAIN"))
+        fprintf(stderr, "sor chain: %d supersteps, rows [%d, %d) .. [%d, %d), most tiles %d (limit %d), resident %d, max waves %d\n", n_steps,
+                steps[0].g_begin, steps[0].g_end, steps[n_steps - 1].g_begin, steps[n_steps - 1].g_end, most, tiles_at_most, resident, max_waves);
+    if (most == 0 || (tiles_at_most > 0 && most > tiles_at_most)) return hipSuccess;
     if ((long)most * SFL_CHAIN_FLAG_STRIDE > (long)flag_words) return hipErrorInvalidValue;
+    if (launched) *launched = true;
     int waves = most;
     if (waves > resident) waves = resident;
     if (max_waves > 0 && waves > max_waves) waves = max_waves;
@@ -973,13 +981,15 @@ SFL_DEFINE_NS(16)
 // The chained launch: its kernels live in translation units of their own (SFL_NS_GROUP 6: fuse 8 and 10, 7: fuse 12 and 16).
 #define SFL_CHAIN_ARGS                                                                                                  \
     hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps, SorParams prm,   \
-        int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out, int max_waves, int *senders
+        int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out, int max_waves, int *senders,        \
+        int tiles_at_most, bool *launched
 #define SFL_DEFINE_CHAIN_PART(N, P, DX1)                                                                                \
     hipError_t launch_sor_chain_ns##N##_p##P(SFL_CHAIN_ARGS)                                                            \
     {                                                                                                                  \
         return launch_chain_variant<Lane2<N, true, false, SFL_CHAIN_ST, SFL_CHAIN_LD>, N, DX1>(s, pa, pb, d, g, steps, n_steps, prm,        \
                                                                            rows_per_chunk, flags, flag_words, epoch,   \
-                                                                           timed_out, max_waves, senders);             \
+                                                                           timed_out, max_waves, senders,              \
+                                                                           tiles_at_most, launched);                   \
     }
 #if SFL_DX_PART == 0
 #define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 0, true)
@@ -1009,8 +1019,9 @@ bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab 
 
 hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
                             int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch,
-                            int *timed_out, int max_waves, int *senders)
+                            int *timed_out, int max_waves, int *senders, int tiles_at_most, bool *launched)
 {
+    if (launched) *launched = false;
     if (n_steps < 1 || n_steps > kMaxChain || !sor_chain_supported(pa, pb, d, g, nsweeps) || flags == nullptr || timed_out == nullptr)
         return hipErrorInvalidValue;
     for (int i = 0; i < n_steps; ++i)
@@ -1019,9 +1030,9 @@ hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d,
 #define SFL_CASE(N)                                                                                                        \
     case N:                                                                                                                \
         return dx1 ? launch_sor_chain_ns##N##_p0(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
-                                                 epoch, timed_out, max_waves, senders)                                     \
+                                                 epoch, timed_out, max_waves, senders, tiles_at_most, launched)            \
                    : launch_sor_chain_ns##N##_p1(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
-                                                 epoch, timed_out, max_waves, senders);
+                                                 epoch, timed_out, max_waves, senders, tiles_at_most, launched);
     switch (nsweeps) {
         SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(16)
     }

@@ -512,7 +512,7 @@ __global__ void wait_count_kernel(const int *count, int target, int *timed_out)
     while ((int)((unsigned)__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)target) < 0) {
         __builtin_amdgcn_s_sleep(20);
         if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
-            if (threadIdx.x == 0) atomicOr(timed_out, 1);
+            if (threadIdx.x == 0) atomicOr(timed_out, 8);
             break;
         }
     }

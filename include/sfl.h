@@ -124,10 +124,15 @@ extern "C" {
                                      subtract_gradient + dye advection of one and velocity advection + divergence of the
                                      next run as ONE kernel (the projected velocity in between is never written to memory);
                                      0 = n times sfl_step.  Same results either way                              */
-#define SFL_OPT_SOR_CHAIN 15       /* kernel 2: 1 = consecutive launches of a solve run as ONE chained launch whose waves go from
-                                     one superstep to the next without a launch boundary, each tile waiting only for the tiles
-                                     around it (fuse depths 8 / 10 / 12 / 16, even dim_x); 0 = one launch per superstep.
-                                     Same results either way                                                       */
+#define SFL_OPT_SOR_CHAIN 15       /* kernel 2: consecutive launches of a solve as ONE chained launch whose waves go from one
+                                     superstep to the next without a launch boundary, each tile waiting only for the tiles
+                                     around it, in-time halo exchanges inside (fuse depths 8 / 10 / 12 / 16, even dim_x).
+                                     0 (default) = one launch per superstep; 1 = wherever it can run; -1 = automatic: slabs
+                                     with a transport of their own (RCCL, the emulated rank) that are thin enough for two
+                                     waves per SIMD to hold their tiles; a value >= 8 = 1 with at most that many waves per
+                                     chain (a test aid: several tiles per wave).  Same results either way; measured -4 .. +3 %
+                                     on the emulated ranks of 8192^2 on 8 GPUs, slower on larger slabs        */
+#define SFL_OPT_LAST_CHAINED 16    /* READ ONLY: supersteps of the last solve that ran inside chained launches          */
 
 typedef struct sfl_context sfl_context;
 

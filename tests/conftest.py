@@ -10,6 +10,11 @@ import sys
 import numpy as np
 import pytest
 
+# The chained launches of several VIRTUAL ranks run side by side, one stream each, and wait for each other's halo messages:
+# every one of those streams needs a hardware queue of its own (the runtime folds streams onto 4 by default).  Read by the
+# HIP runtime when it starts, i.e. before the first test touches the GPU.  (Real ranks are one process per GPU: one chain each.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1078,7 +1078,7 @@ def test_chained_launch_gives_the_same_bits(sfl, oracle, fuse, dim_x, dim_y, row
             s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
             s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
             s.set_option(sfl.capi.OPT_SOR_ROWS, rows)
-            s.set_option(sfl.capi.OPT_SOR_CHAIN, 1)
+            s.set_option(sfl.capi.OPT_SOR_CHAIN, 1 if dx == 1.0 else 64)   # (64: few waves, many tiles per wave)
             s.upload(sfl.capi.FIELD_DIVERGENCE, d)
             for _ in range(2):          # twice: the words of the first chain are still there for the second
                 s.poisson_solve(dx, iters, OMEGA)
@@ -1087,6 +1087,40 @@ def test_chained_launch_gives_the_same_bits(sfl, oracle, fuse, dim_x, dim_y, row
             got = s.download(sfl.capi.FIELD_PRESSURE)
         assert info["fuse"] == fuse and info["launches"] == launches
         assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"chained, fuse {fuse} dx {dx} {dim_x}x{dim_y}")
+
+
+@pytest.mark.parametrize("nranks,dim_x,dim_y,fuse,halo,iters", [
+    (2, 1030, 700, 8, 24, 40), (3, 2048, 1500, 10, 32, 60), (2, 8192, 640, 10, 40, 45), (3, 3000, 1200, 8, 16, 36),
+    (2, 4096, 2048, 10, 0, 80), (3, 1500, 900, 12, 36, 54)])
+def test_chained_launch_across_halo_exchanges(sfl, oracle, nranks, dim_x, dim_y, fuse, halo, iters):
+    """SFL_OPT_SOR_CHAIN on slabs: the in-time halo protocol INSIDE the chained launch -- sender tiles count themselves, the
+    exchange stream copies and raises the arrival count while the chain is running, cut-adjacent tiles of the next superstep
+    poll it, and the tile that overwrites a message's source two supersteps later waits for that message.  Two and three
+    virtual ranks, whose chains run side by side on a stream each; several exchanges inside one chain; pitches that are not
+    whole cache lines; two solves back to back.  Bit for bit the undivided solve -- and the chains really ran."""
+    _, _, d = random_fields(dim_x, dim_y, 300 + fuse + nranks)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
+        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
+        slabs[0].set_option(sfl.capi.OPT_SOR_CHAIN, 1)
+        assert slabs[-1].get_option(sfl.capi.OPT_SOR_CHAIN) == 1
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+        for _ in range(2):
+            slabs[0].poisson_solve(1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        info = slabs[nranks // 2].last_solve_info()
+        chained = slabs[nranks // 2].get_option(sfl.capi.OPT_LAST_CHAINED)
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert chained == info["launches"] - 1 and chained >= 3, (chained, info)
+    assert info["exchanges"] >= 2, info
+    assert_bit_equal(got, want, f"{nranks} slabs, chained launches, fuse {fuse} halo {halo}")
 
 
 SMALL_SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (80, 60), (64, 48), (127, 33), (128, 48), (78, 78),
@@ -1195,6 +1229,44 @@ def test_emulated_rank_runs_its_program_alone(sfl):
         s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
         s.upload(sfl.capi.FIELD_COLOR, bench.synthetic_color(dim_x, s.row_begin, s.row_end))
         for _ in range(3):
+            s.step(DT, 1.0, iters, OMEGA)
+        s.synchronize()
+
+
+@pytest.mark.parametrize("mode,rank", [(1, 3), (-1, 3), (-1, 0), (64, 7)])
+def test_emulated_rank_with_chained_launches(sfl, mode, rank):
+    """The emulated rank with SFL_OPT_SOR_CHAIN: forced, automatic (a thin slab with a transport of its own chains its launches:
+    8192 columns x 1024 rows, the share of BASELINE configuration 4) and with several tiles per wave.  The rows out of the cuts'
+    reach equal the whole-domain solve bit for bit, the chains really ran, whole steps run through."""
+    dim_x, dim_y, nranks, iters = 8192, 8192, 8, 30
+    import bench
+    rows = slice(rank * 1024, (rank + 1) * 1024)
+    rng = np.random.default_rng(5 + rank)
+    d = np.zeros((dim_y, dim_x), np.float32)
+    lo, hi = max(rows.start - 192, 0), min(rows.stop + 192, dim_y)
+    d[lo:hi] = (rng.standard_normal((hi - lo, dim_x)) * 0.1).astype(np.float32)
+    # the whole-domain solve of a right-hand side that is zero away from this slab: only rows within 2 * iters of the slab matter
+    with sfl.Solver(dim_x, dim_y) as one:
+        one.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        one.poisson_solve(1.0, iters, OMEGA)
+        one.synchronize()
+        want = one.download(sfl.capi.FIELD_PRESSURE)[rows]
+    with sfl.Solver(dim_x, dim_y, 0, rank, nranks) as s:
+        s.comm_emulate()
+        s.set_option(sfl.capi.OPT_SOR_CHAIN, mode)
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d[rows])
+        for _ in range(2):
+            s.poisson_solve(1.0, iters, OMEGA)
+        s.synchronize()
+        info = s.last_solve_info()
+        assert s.get_option(sfl.capi.OPT_LAST_CHAINED) == info["launches"] - 1 == 5
+        got = s.download(sfl.capi.FIELD_PRESSURE)
+        reach = 2 * iters
+        inner = slice(reach if rank > 0 else 0, 1024 - (reach if rank < nranks - 1 else 0))
+        assert_bit_equal(got[inner], want[inner], f"emulated rank {rank}, chain mode {mode}: rows out of the cuts' reach")
+        s.upload(sfl.capi.FIELD_VELOCITY, bench.synthetic_velocity(dim_x, s.row_begin, s.row_end))
+        s.upload(sfl.capi.FIELD_COLOR, bench.synthetic_color(dim_x, s.row_begin, s.row_end))
+        for _ in range(2):
             s.step(DT, 1.0, iters, OMEGA)
         s.synchronize()
 

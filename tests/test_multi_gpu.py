@@ -23,10 +23,12 @@ def _devices():
 # (8, 8192, 80) is BASELINE config 4, (2 / 4, 8192, 80) its other scaling points, (8, 16384, 200) config 5 -- exactly as
 # bench.py runs them; the smaller grids exercise classic (halo < 2 x fuse) and early exchanges, with and without overlap
 # overlap: 1 = exchanges on the second stream, the halo's arrival counted on the device (the default), 2 = the same with a
-# cross-stream event in front of the launch that needs it (SFL_OPT_SOR_ARRIVAL = 0), 0 = in line
+# cross-stream event in front of the launch that needs it (SFL_OPT_SOR_ARRIVAL = 0), 0 = in line; 3 = as 1 with chained launches where the slabs
+# are thin (--chain -1), 4 = as 1 with chained launches wherever they can run (--chain 1)
 @pytest.mark.parametrize("nranks,size,iters,halo,overlap", [
     (2, 2048, 40, 0, 1), (2, 2048, 40, 0, 2), (2, 1024, 24, 16, 1), (2, 1024, 24, 12, 0), (4, 2048, 40, 0, 1), (8, 4096, 30, 0, 1),
-    (2, 8192, 80, 0, 1), (4, 8192, 80, 0, 1), (8, 8192, 80, 0, 1), (8, 8192, 80, 0, 2), (8, 8192, 80, 0, 0), (8, 16384, 200, 0, 1)])
+    (2, 8192, 80, 0, 1), (4, 8192, 80, 0, 1), (8, 8192, 80, 0, 1), (8, 8192, 80, 0, 2), (8, 8192, 80, 0, 0), (8, 8192, 80, 0, 3),
+    (2, 2048, 40, 0, 4), (4, 8192, 80, 0, 4), (8, 16384, 200, 0, 1)])
 def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, overlap):
     if _devices() < nranks:
         pytest.skip(f"needs {nranks} GPUs, {_devices()} visible")
@@ -38,6 +40,8 @@ def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, overlap):
         cmd += ["--no-overlap"]
     if overlap == 2:
         cmd += ["--arrival-by-event"]
+    if overlap in (3, 4):
+        cmd += ["--chain", "-1" if overlap == 3 else "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode == 0, r.stderr[-4000:]

@@ -2,7 +2,8 @@
 # First thing to run on a node with more than one MI355X: the RCCL path with N > 1 has only ever been
 # exercised on one-GPU boxes (virtual ranks, an emulated rank, a one-rank communicator).
 #   1. the multi-GPU tests (BASELINE configs 4 and 5 exactly, 2- and 4-rank points, with and without overlap);
-#   2. bench.py at 1 / 2 / 4 / 8 GPUs: overlapped with the device-side arrival count, overlapped with events, in line --
+#   2. bench.py at 1 / 2 / 4 / 8 GPUs: exchanges in time, the same inside chained launches where the slabs are thin
+#      (--chain -1), early exchanges behind events, in line --
 #      the ranks are started as fresh child processes by bench.py's own launcher (its parent never touches a GPU);
 #   3. RCCL's own report of the ranks (NCCL_DEBUG=INFO of the 2-GPU run: "comm ... nranks 2" per rank);
 #   4. a rocprofv3 kernel trace of rank 0 at the largest N (the launcher's children are traced through torch.distributed.run's
@@ -19,12 +20,12 @@ if [ "$NG" -lt 2 ]; then echo "needs at least 2 GPUs" | tee -a $O/summary.txt; e
 tail -3 $O/pytest_multi_gpu.log | tee -a $O/summary.txt
 for n in 1 2 4 8; do
   [ $n -le $NG ] || continue
-  for mode in "" "--arrival-by-event" "--no-overlap"; do
+  for mode in "" "--chain -1" "--arrival-by-event" "--no-overlap"; do
     tag=n${n}$(echo "$mode" | tr -d ' -')
     timeout 900 python3 bench.py --gpus $n --steps 10 --warmup 3 $mode > $O/bench_$tag.json 2> $O/bench_$tag.err || tail -3 $O/bench_$tag.err
     python3 -c "
 import json; d = json.load(open('$O/bench_$tag.json'))
-print('%-28s %d GPU(s): %.3e cell-iters/s  %.4f ms per solve  %s sim steps/s  parity %s  exchanges per solve %s' % ('${mode:-overlap + arrival count}', d['n_gpus'], d['value'], d['ms_per_step'], d['sim_steps_per_sec'], (d.get('parity') or {}).get('bit_exact'), d['config']['halo_exchanges_per_solve']))" | tee -a $O/summary.txt
+print('%-34s %d GPU(s): %.3e cell-iters/s  %.4f ms per solve  %s sim steps/s  parity %s  exchanges per solve %s' % ('${mode:-in time}', d['n_gpus'], d['value'], d['ms_per_step'], d['sim_steps_per_sec'], (d.get('parity') or {}).get('bit_exact'), d['config']['halo_exchanges_per_solve']))" | tee -a $O/summary.txt
   done
 done
 NCCL_DEBUG=INFO timeout 600 python3 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --sim-steps 0 > /dev/null 2> $O/rccl_info_n2.log
