@@ -507,7 +507,10 @@ def run_rank(args):
             s.poisson_solve(1.0, iters, omega)
     elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
-    info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
+    try:
+        info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
+    except sfl.SflError:                                        # (an older library under tools/with_lib.py)
+        info["chained"] = 0
 
     # ---- parity of the timed configuration: the p the last timed solve left behind is downloaded
     # NOW (with the right-hand side it was solved for); the reference CPU loop runs after all GPU
