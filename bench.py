@@ -75,6 +75,17 @@ def synthetic_velocity(dim_x, row_begin, row_end, seed=12345, vamp=100.0):
     return out
 
 
+def slab_checksums(fields):
+    """Two 64-bit sums (wrapping) per field over its 4-byte words: plain, and weighted by (position mod 65521) + 1 -- what the ranks
+    of a multi-GPU run compare instead of shipping 1.5 GB of fields."""
+    out = []
+    for a in fields:
+        w = np.ascontiguousarray(a).view(np.uint32).ravel().astype(np.uint64)
+        k = (np.arange(w.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        out.append([int(w.sum(dtype=np.uint64)), int((w * k).sum(dtype=np.uint64))])
+    return out
+
+
 def synthetic_color(dim_x, row_begin, row_end, seed=777):
     j = np.arange(row_begin, row_end, dtype=np.uint64)[:, None, None]
     i = np.arange(dim_x, dtype=np.uint64)[None, :, None]
@@ -270,6 +281,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the reference CPU solve (and with it the parity check)")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the reference solve on rank 0")
+    ap.add_argument("--check-sim-step-parity", action="store_true",
+                    help="N = 1: run the sim-step field check of the multi-GPU path as well (rank 0 replays the steps on a second, "
+                         "whole-domain context; every rank compares checksums of its rows) -- always on for N > 1")
     ap.add_argument("--no-priming", action="store_true",
                     help="skip the ~80 ms of untimed solves that bring the GPU to its sustained clocks")
     ap.add_argument("--advect-kernel", type=int, default=0,
@@ -565,6 +579,44 @@ def run_rank(args):
             if not bad_step:
                 sim_sps = args.sim_steps / sim_tn
 
+    # ---- the sim step's fields across ranks: the slabs' velocity, colour and pressure after all those steps against
+    # the same steps on ONE whole-domain context, which rank 0 runs on its own GPU (that path is checked against the reference CPU
+    # code by the one-GPU run and the test suite); compared through per-slab checksums.  Collective calls stay outside every
+    # try: a rank that fails locally still takes part, and the bench line is never lost to the checker.
+    step_parity = None
+    if args.sim_steps > 0 and sim_sps is not None and not emulate and not args.no_parity and (world > 1 or args.check_sim_step_parity):
+        names = (capi.FIELD_VELOCITY, capi.FIELD_COLOR, capi.FIELD_PRESSURE)
+        mine, err = None, None
+        try:
+            mine = slab_checksums([s.download(f) for f in names])
+        except Exception as e:   # noqa: BLE001
+            err = repr(e)
+        spans = rdzv.all_gather([s.row_begin, s.row_end])
+        want = None
+        if rank == 0:
+            try:
+                with sfl.Solver(size, dim_y, device=local_rank) as ref:
+                    ref.upload(capi.FIELD_VELOCITY, synthetic_velocity(size, 0, dim_y))
+                    ref.upload(capi.FIELD_COLOR, synthetic_color(size, 0, dim_y))
+                    for _ in range((1 if args.no_priming else 12) + args.sim_steps):
+                        ref.step(dtf, 1.0, iters, omega)
+                    ref.step_n(args.sim_steps, dtf, 1.0, iters, omega)
+                    ref.synchronize()
+                    whole = [ref.download(f) for f in names]
+                want = [slab_checksums([f[b:e] for f in whole]) for b, e in spans]
+                del whole
+            except Exception as e:   # noqa: BLE001
+                err = repr(e)
+        want = rdzv.all_gather(want)[0]
+        same = rdzv.all_gather(None if (want is None or mine is None) else bool(want[rank] == mine))
+        errs = [e for e in rdzv.all_gather(err) if e]
+        if errs or any(x is None for x in same):
+            step_parity = {"error": errs[0] if errs else "no checksums"}
+        else:
+            step_parity = {"what": f"velocity, colour and pressure after {(1 if args.no_priming else 12) + 2 * args.sim_steps} sim steps: "
+                                   "every rank's rows against the same steps on one whole-domain context (rank 0's GPU), by checksums",
+                           "bit_exact": all(same), "ranks_differing": [r for r, ok in enumerate(same) if not ok]}
+
     op_us = None
     if world == 1 and args.sim_steps > 0:
         op_us = gpu_operator_times(s, iters, cells)
@@ -713,6 +765,7 @@ def run_rank(args):
                        "halo_exchanges_per_solve": info["exchanges"],
                        "half_sweeps_fused_per_launch": info["fuse"]},
             "parity": parity,
+            **({"sim_step_parity": step_parity} if step_parity is not None else {}),
             "roofline": roofline,
             "sim_steps_per_sec": sim_sps,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None,
@@ -748,6 +801,9 @@ def run_rank(args):
         if parity and not parity["bit_exact"]:
             print(f"bench.py: PARITY FAILURE: {parity['mismatching_cells']} cells differ from the "
                   f"reference", file=sys.stderr)
+            rc = 3
+        if step_parity and step_parity.get("bit_exact") is False:
+            print(f"bench.py: PARITY FAILURE of the sim step's fields on ranks {step_parity['ranks_differing']}", file=sys.stderr)
             rc = 3
 
     rdzv.barrier()

@@ -2,6 +2,8 @@
 golden fixtures and against the oracle on seeded inputs.  Bit-exact everywhere: the kernels are
 built with -ffp-contract=off, so the 1e-5 relative tolerance north_star allows for fp32 fields is
 met with 0 ulp; UQ32 / index / interpolation arithmetic must be bit-exact by contract."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1269,6 +1271,25 @@ def test_emulated_rank_with_chained_launches(sfl, mode, rank):
         for _ in range(2):
             s.step(DT, 1.0, iters, OMEGA)
         s.synchronize()
+
+
+def test_bench_checks_the_sim_steps_fields_across_ranks():
+    """bench.py's check of the sim step's fields for N > 1 (every rank's rows against the same steps on one whole-domain context
+    on rank 0's GPU, by checksums), run here with its one-GPU switch: the replay takes the same number of steps, the checksums of
+    equal fields agree, the line carries the verdict."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "640", "--dim-y", "512", "--iters", "10", "--steps", "2",
+                        "--warmup", "1", "--sim-steps", "3", "--no-priming", "--check-sim-step-parity"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    sp = out.get("sim_step_parity")
+    assert sp and sp.get("bit_exact") is True and sp["ranks_differing"] == [], sp
+    assert "after 7 sim steps" in sp["what"]
+    assert out["parity"]["bit_exact"]
 
 
 # ---- round 4: the BASELINE multi-GPU configurations in full on eight virtual ranks -----------------------------

@@ -50,3 +50,5 @@ def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, overlap):
     assert out["parity"]["bit_exact"] and out["parity"]["cells"] == size * size
     assert out["config"]["halo_exchanges_per_solve"] > 0
     assert out["sim_steps_per_sec"] is not None, out.get("sim_steps_note")
+    # the sim step's fields: every rank's rows against the same steps on one whole-domain context
+    assert out.get("sim_step_parity", {}).get("bit_exact") is True, out.get("sim_step_parity")
