@@ -23,6 +23,7 @@ OPT_SOR_ARRIVAL = 13
 OPT_STEP_SEAMS = 14
 OPT_SOR_CHAIN = 15
 OPT_LAST_CHAINED = 16
+OPT_LAST_EARLY_ROWS = 17
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128

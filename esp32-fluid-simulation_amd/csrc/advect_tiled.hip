@@ -379,7 +379,11 @@ gradient_tiled_kernel(float2 *v, const float *__restrict__ p, Slab g, TileGrid t
 // question).  FUSE_GRAD as in stencil_kernels.hip: the projection of the cell's own velocity
 // (finitediff.cpp:41-82) happens here, in place, before the back-trace -- and before the barrier, so
 // that the loads of v and p travel together with those of the window.
-template <bool NO_SLIP, bool FUSE_GRAD, int THREADS>
+// REACH (slabs, FUSE_GRAD): the back-traces of this kernel are those of the NEXT step's velocity advection -- same projected
+// velocity, same dt, same rows -- so the kernel also leaves what backtrace_reach_kernel would measure afterwards (three launches,
+// 31 us on a 1024-row slab, on the critical path between two steps): `halo_flag` then points at word [2] of a reach report
+// (sfl_api.cpp kReachWords) and words [0], [1], [3] .. [7] are raised with atomicMax, one per wave and word.
+template <bool NO_SLIP, bool FUSE_GRAD, int THREADS, bool REACH = false>
 __global__ void __launch_bounds__(THREADS)
 advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 *vel, Slab g, Slab gs,
                              TileGrid tg, int g_begin, int g_end, int valid_begin, int valid_end, float dt,
@@ -439,15 +443,32 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
     }
     __syncthreads();
 
-    if (!column) return;
+    if (!REACH && !column) return;
+    int need[7] = {0, 0, 0, 0, 0, 0, 0};   // REACH: report words [0], [1], [4], [5], [6], [7], [3]
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
         const int gj = y0 + wave + kWaves * r;
-        if (gj >= g_end) break;
+        if (gj >= g_end || !column) break;
         const float2 u = own[r];
         const float si = (float)i - u.x * dt;
         const float sj = (float)gj - u.y * dt;
         const SrcPos s = classify(si, sj, g.dim_x, g.gdim_y);
+        if (REACH) {   // exactly backtrace_reach_kernel's expressions for rows [g_begin, g_end), [g_begin, g_begin + 1), [g_end - 1, g_end)
+            const int top = s.cj + (s.y_oob ? 0 : 1);
+            need[0] = max(need[0], g_begin - s.cj);
+            need[1] = max(need[1], top - (g_end - 1));
+            if (gj == g_begin) {   // (wave-uniform)
+                need[2] = max(need[2], g_begin - s.cj);
+                need[3] = max(need[3], top - g_begin);
+            }
+            if (gj == g_end - 1) {
+                need[4] = max(need[4], g_end - 1 - s.cj);
+                need[5] = max(need[5], top - (g_end - 1));
+            }
+            // [3]: how many rows from its own row a cell's sources lie at most -- rows further than that from both ends of the
+            // slab never read beyond it (sfl_api.cpp advect_interior_early)
+            need[6] = max(need[6], max(gj - s.cj, top - gj));
+        }
         if (!rows_available(s, valid_begin, valid_end)) {
             if (halo_flag) atomicOr(halo_flag, 1);
             continue;
@@ -471,6 +492,25 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
         o[0] = res.x;
         o[1] = res.y;
         o[2] = res.z;
+    }
+    if (REACH) {   // every lane of the block is here again: one look at each word per BLOCK (word [3] is positive in every wave:
+                   // an atomic per wave on it took 330 us, a look per wave still 50), an atomic only where there is something to add
+        __syncthreads();   // (the window is no longer read: its LDS takes the waves' maxima)
+        int *scratch = reinterpret_cast<int *>(tile);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            int v = need[k];
+            for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+            if (lane == 0) scratch[wave * 8 + k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            int v = 0;
+            for (int w2 = 0; w2 < kWaves; ++w2) v = max(v, scratch[w2 * 8 + k]);
+            int *word = halo_flag - 2 + (k < 2 ? k : k < 6 ? k + 2 : 3);
+            if (v > 0 && v > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, v);
+        }
     }
 }
 
@@ -766,13 +806,23 @@ hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *
 hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const uint32_t *p, float *vel,
                                         const float *pressure, Slab g, int g_begin, int g_end, int valid_begin,
                                         int valid_end, float dt, bool no_slip, int *halo_flag,
-                                        float two_dx_inv, const Slab *src)
+                                        float two_dx_inv, const Slab *src, bool reach)
 {
     if (g_end <= g_begin) return hipSuccess;
     const Slab gs = src ? *src : g;
     const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
     const dim3 grid(tg.per_xcd * kXcds), block(kThreadsDye);
     auto *vi = reinterpret_cast<float2 *>(vel);
+    if (reach) {   // (see the kernel: halo_flag = word [2] of a reach report, the projection fused in)
+        if (!pressure || !halo_flag || src) return hipErrorInvalidValue;
+        if (no_slip)
+            advect_vec3uq32_tiled_kernel<true, true, kThreadsDye, true><<<grid, block, 0, s>>>(
+                next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
+        else
+            advect_vec3uq32_tiled_kernel<false, true, kThreadsDye, true><<<grid, block, 0, s>>>(
+                next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv);
+        return hipGetLastError();
+    }
 #define SFL_GO(NS_, FG_)                                                                                    \
     advect_vec3uq32_tiled_kernel<NS_, FG_, kThreadsDye><<<grid, block, 0, s>>>(                             \
         next_p, p, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, pressure, two_dx_inv)

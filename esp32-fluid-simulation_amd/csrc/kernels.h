@@ -45,7 +45,11 @@ hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, S
 hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                           float *vel, const float *pressure, Slab g, int g_begin,
                                           int g_end, int valid_begin, int valid_end, float dt,
-                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel = 0);
+                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel = 0,
+                                          bool *reach_measured = nullptr);
+// `reach_measured` != nullptr (slabs; halo_flag = word [2] of a reach report, zeroed): when the tile kernel runs it also leaves the
+// reach of the projected velocity's back-traces in the report's other words -- what launch_backtrace_reach would measure in three
+// launches afterwards -- and sets *reach_measured; the one-thread-per-cell kernel does not.
 
 // `kernel` of the three launchers above: 1 = one thread per cell with a 4-texel gather from memory
 // (stencil_kernels.hip), 2 = the source window of a 64 x 32 tile staged in LDS (advect_tiled.hip),
@@ -58,7 +62,7 @@ hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *
 hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const uint32_t *p, float *vel,
                                         const float *pressure, Slab g, int g_begin, int g_end, int valid_begin,
                                         int valid_end, float dt, bool no_slip, int *halo_flag,
-                                        float two_dx_inv, const Slab *src);
+                                        float two_dx_inv, const Slab *src, bool reach = false);
 // advect(v_next, v, v) (ino:252-256) and calculate_divergence(div, v_next) (ino:274) in one pass of a
 // WHOLE-DOMAIN context (grow0 = 0, lrows = gdim_y): the advected tile and the ring around it are
 // differenced in LDS.  Same arithmetic as the two operators, same bits.

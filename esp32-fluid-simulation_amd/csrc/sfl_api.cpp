@@ -144,6 +144,15 @@ struct sfl_context {
     // land in pinned host memory behind ev_report, and are examined when the NEXT call touches the context
     int *d_report = nullptr;       // device reach words (launch_reach_set) with the flag in word [2]
     int *h_report = nullptr;       // pinned host copy
+    bool reach_in_report = false;  // the dye's kernel of this step has left the reach words in d_report already
+    // slab_step_auto: the rows further than `early_rows` from both cuts were advected into vel_tmp BEFORE the host waited for the
+    // last step's report (advect_interior_early); valid for the velocity of vel_epoch == early_epoch at early_dt
+    int early_rows = 0;
+    uint64_t early_epoch = 0;
+    float early_dt = 0.0f;
+    bool disp_in_report = false;   // the pending report carries word [3] (the tile kernel measured it)
+    int last_early_kept = 0;       // slab_step_auto: rows from each cut beyond which the last step kept the early advection (0: none)
+    int known_disp = -1;           // rows a cell's sources lie from its own row at most, for the velocity of known_epoch (-1: unknown)
     hipEvent_t ev_report = nullptr;
     hipEvent_t ev_color_halo = nullptr;  // the dye's halo, sent at the START of a step (slab_step_auto), has arrived
     bool color_unsettled = false;  // a dye advection on a guessed halo has not been checked yet
@@ -1354,7 +1363,8 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_TRANSPORT:
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
         case SFL_OPT_LAST_CHAINED:
-            return fail(SFL_ERR_INVALID, "SFL_OPT_LAST_CHAINED is read-only");
+        case SFL_OPT_LAST_EARLY_ROWS:
+            return fail(SFL_ERR_INVALID, "this option is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
@@ -1436,6 +1446,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_STEP_SEAMS: *value = c->opt_step_seams; return SFL_OK;
         case SFL_OPT_SOR_CHAIN: *value = c->opt_sor_chain; return SFL_OK;
         case SFL_OPT_LAST_CHAINED: *value = c->last_chained; return SFL_OK;
+        case SFL_OPT_LAST_EARLY_ROWS: *value = c->last_early_kept; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
 }
@@ -1807,7 +1818,7 @@ int gather_field(sfl_context *ctx, const std::vector<sfl_context *> &peers, int 
 static int settle_color(sfl_context *ctx);
 
 static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
-                                   const AdvectPlan &plan, int extend = 0);
+                                   const AdvectPlan &plan, int extend = 0, int interior_done = 0);
 
 int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
 {
@@ -1825,8 +1836,10 @@ int sfl_advect_velocity(sfl_context *ctx, float dt, int no_slip)
 
 // `extend` = 1 (slab_step_auto; plan.halo then covers one row more than the reach): the ghost rows next to the cuts
 // are advected as well, redundantly -- calculate_divergence then needs no exchange of its own.
+// `interior_done` = L > 0 (slab_step_auto): rows [g0 + L, g1 - L) are in vel_tmp already (advect_interior_early): only the two
+// bands next to the cuts, the rows that may need the halo, are advected here.
 static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt, int no_slip,
-                                   const AdvectPlan &plan, int extend)
+                                   const AdvectPlan &plan, int extend, int interior_done)
 {
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
@@ -1843,7 +1856,14 @@ static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_conte
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, static_cast<const float *>(c->gather_buf),
                                              c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
                                              nullptr, &whole, c->opt_advect_kernel));
-        else
+        else if (interior_done > 0) {
+            for (int band = 0; band < 2; ++band)
+                HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom,
+                                                 band ? c->g1 - interior_done : clip_lo(c, c->g0 - extend),
+                                                 band ? clip_hi(c, c->g1 + extend) : c->g0 + interior_done,
+                                                 clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
+                                                 no_slip != 0, advect_flag(c, plan), nullptr, c->opt_advect_kernel));
+        } else
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom,
                                              clip_lo(c, c->g0 - extend), clip_hi(c, c->g1 + extend),
                                              clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
@@ -2097,10 +2117,12 @@ static int project_and_advect_color(sfl_context *ctx, float dt, float dx, int ha
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         const int h = c->nranks > 1 ? halo : 0;
+        // (with a report the tile kernel also measures the reach of the projected velocity: post_reach_report)
+        c->reach_in_report = false;
         HIP_TRY(sfl::launch_project_advect_vec3uq32(
             c->stream, c->col_tmp, c->col, c->vel, c->p, c->geom, c->g0, c->g1, clip_lo(c, c->g0 - h),
             clip_hi(c, c->g1 + h), dt, false, c->nranks > 1 ? (report ? c->d_report + 2 : c->halo_flag) : nullptr,
-            two_dx_inv, c->opt_advect_kernel));
+            two_dx_inv, c->opt_advect_kernel, c->nranks > 1 && report ? &c->reach_in_report : nullptr));
         std::swap(c->col, c->col_tmp);  // ino:286
         ++c->vel_epoch;                 // the projection rewrote the velocity
         c->v_ghost_valid = 0;
@@ -2198,7 +2220,11 @@ static int ensure_report(sfl_context *c)
 // the advection kernel before), reduce over the ranks, start the copy to the host.  No host wait.
 static int post_reach_report(sfl_context *ctx, const std::vector<sfl_context *> &peers, float dt)
 {
-    for (sfl_context *c : peers) SFL_TRY(launch_reach_set(c, c->d_report, dt));
+    for (sfl_context *c : peers) {   // (unless the dye's kernel has measured it on the way: project_and_advect_color)
+        if (!c->reach_in_report) SFL_TRY(launch_reach_set(c, c->d_report, dt));
+        c->disp_in_report = c->reach_in_report;
+        c->reach_in_report = false;
+    }
     if (ctx->comm) {  // maximum over the ranks, on the exchange stream like every RCCL operation
         Overlap o;
         SFL_TRY(overlap_of(ctx, &o));
@@ -2228,17 +2254,19 @@ static int settle_color(sfl_context *ctx)
     if (ctx->comm && ctx->options_dirty) SFL_TRY(sfl_comm_check_options(ctx));   // (collective; see sfl_set_option)
     if (!ctx->color_unsettled) return SFL_OK;
     std::vector<sfl_context *> peers = peers_of(ctx);
-    int reach = 0, reach_ext = 0, flag = 0;
+    int reach = 0, reach_ext = 0, flag = 0, disp = 0;
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipEventSynchronize(c->ev_report));  // (the step it belongs to has long been queued; no stream is drained)
         reach = std::max(reach, reach_own(c->h_report));
         reach_ext = std::max(reach_ext, reach_extended(c->h_report));
         flag |= c->h_report[2];
+        disp = c->disp_in_report && disp >= 0 ? std::max(disp, c->h_report[3]) : -1;
         c->color_unsettled = false;
     }
     const float dt = ctx->unsettled_dt;
     for (sfl_context *c : peers) {  // the reach of the back-traces of the velocity as it stands now
+        c->known_disp = disp;
         c->known_reach = reach;
         c->known_reach_ext = reach_ext;
         c->known_epoch = c->vel_epoch;
@@ -2274,21 +2302,6 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     } else {  // first step, or the velocity was written from outside: one measured advection (a host round trip)
         SFL_TRY(measure_reach(ctx, peers, dt, &reach_v, &reach_v_ext));
     }
-    // The dye is not touched before the end of the step and its halo is a guess made from what is known NOW (the
-    // projection changes the velocity a little, forces may change it a lot: checked after the step): send it at
-    // once, on the exchange stream, under the velocity advection and the solve.
-    const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
-    {
-        for (sfl_context *c : peers) {
-            SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
-            SFL_TRY(ensure(c, c->col_tmp, 12, false));
-        }
-        Overlap o;
-        SFL_TRY(overlap_of(ctx, &o));
-        SFL_TRY(start_exchange(peers, o, SFL_FIELD_COLOR, guess, 0, false));
-        SFL_TRY(use_device(ctx));
-        HIP_TRY(hipEventRecord(ctx->ev_color_halo, o.xstream));
-    }
     // Two of the step's small exchanges are traded for one redundant row each: the velocity advection also advects
     // the ghost row next to each cut (halo = reach_extended: the neighbours' edge rows trace into THEIR slabs), so calculate_divergence finds
     // its neighbours' rows in place; and the solve leaves one ghost row of p exact (plan tail), which is all
@@ -2306,7 +2319,31 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     } else {
         pv.gather = true;
     }
-    SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv, extend));        // ino:252-256, exact halo
+    // (rows out of the cuts' reach may be in vel_tmp already, advected while the host was waiting for the report: sfl_step)
+    int interior_done = 0;
+    if (known && extend && !pv.gather && ctx->early_rows > 0 && ctx->early_epoch == ctx->vel_epoch && ctx->early_dt == dt &&
+        ctx->known_disp >= 0 && ctx->known_disp <= ctx->early_rows && pv.halo <= ctx->early_rows)
+        interior_done = ctx->early_rows;   // no cell of those rows read beyond the slab: what is in vel_tmp is the advection
+    for (sfl_context *c : peers) {
+        c->early_rows = 0;
+        c->last_early_kept = interior_done;
+    }
+    SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv, extend, interior_done));   // ino:252-256, exact halo
+    // The dye is not touched before the end of the step and its halo is a guess made from what was known at the START of the
+    // step (the projection changes the velocity a little, forces may change it a lot: checked after the step): sent now, on
+    // the exchange stream, under the solve -- behind the velocity's halo and advection, which the step is waiting for.
+    const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
+    {
+        for (sfl_context *c : peers) {
+            SFL_TRY(ensure_field(c, SFL_FIELD_COLOR));
+            SFL_TRY(ensure(c, c->col_tmp, 12, false));
+        }
+        Overlap o;
+        SFL_TRY(overlap_of(ctx, &o));
+        SFL_TRY(start_exchange(peers, o, SFL_FIELD_COLOR, guess, 0, false));
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(hipEventRecord(ctx->ev_color_halo, o.xstream));
+    }
     for (sfl_context *c : peers) SFL_TRY(apply_queued_forces(c));           // ino:264-269
     SFL_TRY(sfl_calculate_divergence(ctx, dx));                             // ino:274
     for (sfl_context *c : peers) c->solve_tail = 1;
@@ -2331,9 +2368,33 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
     return post_reach_report(ctx, peers, dt);
 }
 
+// slab_step_auto's host has to read the last step's report (the reach of the projected velocity: the halo of this step's
+// velocity advection; whether the dye's guess held) before it can queue the step -- 25 - 60 us in which the GPU has nothing to do.
+// The rows further than the largest possible halo from both cuts need no halo at all: their advection is queued BEFORE the wait.
+// The report also says how far from its own row any cell's sources lie (word [3], from the dye's kernel): within that halo,
+// those rows never read beyond the slab and what was advected early stands; otherwise the step advects everything again.
+static int advect_interior_early(sfl_context *ctx, float dt)
+{
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    const int limit = std::min(kGhostRows, min_owned_rows(ctx));
+    for (sfl_context *c : peers)
+        if (!c->vel || !c->vel_tmp || c->g1 - c->g0 < 2 * limit + 64) return SFL_OK;   // (nothing worth it, or not set up yet)
+    for (sfl_context *c : peers) {
+        SFL_TRY(use_device(c));
+        HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0 + limit, c->g1 - limit, c->g0,
+                                         c->g1, dt, true, nullptr, nullptr, c->opt_advect_kernel));
+        c->early_rows = limit;
+        c->early_epoch = c->vel_epoch;
+        c->early_dt = dt;
+    }
+    return SFL_OK;
+}
+
 int sfl_step(sfl_context *ctx, float dt, float dx, int iters, float omega)
 {
     if (!ctx) return fail(SFL_ERR_INVALID, "ctx is NULL");
+    if (ctx->nranks > 1 && ctx->opt_advect_halo == 0 && ctx->color_unsettled && ctx->unsettled_dt == dt && ctx->force_cells.empty())
+        SFL_TRY(advect_interior_early(ctx, dt));
     SFL_TRY(settle_color(ctx));
     if (small_grid(ctx)) return small_grid_step(ctx, dt, dx, iters, omega);
     if (ctx->nranks > 1 && ctx->opt_advect_halo == 0) return slab_step_auto(ctx, dt, dx, iters, omega);

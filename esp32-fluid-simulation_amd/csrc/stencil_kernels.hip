@@ -367,12 +367,16 @@ hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_
 hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                           float *vel, const float *pressure, Slab g, int g_begin,
                                           int g_end, int valid_begin, int valid_end, float dt,
-                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel)
+                                          bool no_slip, int *halo_flag, float two_dx_inv, int kernel, bool *reach_measured)
 {
+    if (reach_measured) *reach_measured = false;
     if (g_end <= g_begin) return hipSuccess;
-    if (use_tiled_advect(kernel, g, g_begin, g_end))
+    if (use_tiled_advect(kernel, g, g_begin, g_end)) {
+        const bool reach = reach_measured != nullptr && halo_flag != nullptr;
+        if (reach) *reach_measured = true;
         return launch_advect_vec3uq32_tiled(s, next_p, p, vel, pressure, g, g_begin, g_end, valid_begin,
-                                            valid_end, dt, no_slip, halo_flag, two_dx_inv, nullptr);
+                                            valid_end, dt, no_slip, halo_flag, two_dx_inv, nullptr, reach);
+    }
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *vi = reinterpret_cast<float2 *>(vel);
     if (no_slip)

@@ -133,6 +133,10 @@ extern "C" {
                                      chain (a test aid: several tiles per wave).  Same results either way; measured -4 .. +3 %
                                      on the emulated ranks of 8192^2 on 8 GPUs, slower on larger slabs        */
 #define SFL_OPT_LAST_CHAINED 16    /* READ ONLY: supersteps of the last solve that ran inside chained launches          */
+#define SFL_OPT_LAST_EARLY_ROWS 17 /* READ ONLY: slabs on the automatic advection halo: L > 0 when the last sfl_step kept the velocity
+                                     advection of the rows further than L from both cuts that it had queued BEFORE reading the
+                                     previous step's report (they need no halo; the report says whether that held); 0 = the step
+                                     advected everything after the report                                            */
 
 typedef struct sfl_context sfl_context;
 

@@ -894,6 +894,46 @@ def test_slab_steps_on_the_automatic_halo_without_mid_step_round_trips(sfl, orac
             s.close()
 
 
+@pytest.mark.parametrize("nranks,jet", [(2, 0.0), (2, 80.0), (3, 70.0), (3, 0.0)])
+def test_early_interior_advection_is_kept_only_where_it_holds(sfl, oracle, nranks, jet):
+    """sfl_step on slabs queues the velocity advection of the rows further than 64 from both cuts BEFORE the host reads the
+    previous step's report (those rows need no halo); the report's word [3] -- how far from its own row any cell's sources lie,
+    measured by the dye's kernel together with the reach -- says whether that held.  Calm flow: kept from the second step on.
+    With a jet of 70 / 80 rows per step just inside that zone (its back-traces cross the cut; the reach, 4 - 14 rows, would have
+    let it pass) the early rows are dropped and everything is advected after the report.  Four steps back to back, every field
+    against the oracle."""
+    dim_x, rows, iters = 256, 320, 6
+    dim_y = rows * nranks
+    v, c, _ = random_fields(dim_x, dim_y, 500 + nranks, 40.0)          # |v dt| <= 1.4 rows
+    if jet:
+        for r in range(1, nranks):
+            v[r * rows + 66:r * rows + 76, 40:200, 1] = jet / float(DT)     # upwards: sources `jet` rows below, across the cut
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    kept = []
+    try:
+        sfl.Solver.link_group(slabs)
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        for k in range(4):      # back to back: nothing touches the contexts in between, every step finds a report pending
+            slabs[0].step(DT, 1.0, iters, OMEGA)
+            kept.append(slabs[1].get_option(sfl.capi.OPT_LAST_EARLY_ROWS))
+            v, d, p, c = oracle.step(v, c, DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        assert_bit_equal(cat(sfl.capi.FIELD_VELOCITY), v, f"{nranks} slabs, jet {jet}: velocity after 4 steps")
+        assert_bit_equal(cat(sfl.capi.FIELD_COLOR), c, f"{nranks} slabs, jet {jet}: colour after 4 steps")
+        assert_bit_equal(cat(sfl.capi.FIELD_PRESSURE), p, f"{nranks} slabs, jet {jet}: pressure after 4 steps")
+    finally:
+        for s in slabs:
+            s.close()
+    assert kept[0] == 0                      # the first step measures before it advects
+    if jet:
+        assert kept[1] == 0, kept            # the jet's sources lie further than 64 rows from their cells
+    else:
+        assert kept[1:] == [64, 64, 64], kept
+
+
 def _smooth_velocity(dim_x, dim_y, amp):
     """Solid-body swirl + a shear: neighbouring cells back-trace to neighbouring texels (what a
     simulation has, as opposed to random_fields' per-cell noise)."""
