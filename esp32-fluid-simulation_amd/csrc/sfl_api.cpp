@@ -155,6 +155,8 @@ struct sfl_context {
     int known_disp = -1;           // rows a cell's sources lie from its own row at most, for the velocity of known_epoch (-1: unknown)
     hipEvent_t ev_report = nullptr;
     hipEvent_t ev_color_halo = nullptr;  // the dye's halo, sent at the START of a step (slab_step_auto), has arrived
+    hipEvent_t ev_vel_final = nullptr;   // recorded in front of the early interior advection (advect_interior_early)
+    bool vel_final_recorded = false;     // ... in the step that is being queued
     bool color_unsettled = false;  // a dye advection on a guessed halo has not been checked yet
     float unsettled_dt = 0.0f;
     int known_reach = -1;          // reach of the back-traces of the CURRENT velocity at known_dt (-1: unknown)
@@ -629,13 +631,24 @@ int await_exchange(const std::vector<sfl_context *> &peers, const Overlap &o)
 // An exchange IN LINE with the compute stream's work.  With RCCL it still travels on the exchange
 // stream -- every operation of a communicator is issued to ONE stream, whatever the operator --
 // bracketed by the two events; in-process copies of a linked group go on the compute stream itself.
-int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows, int skip = 0)
+// `after` != nullptr: the exchanged rows were final when that event was recorded on the compute stream -- the exchange starts
+// behind IT, not behind what has been queued on the compute stream since (slab_step_auto's early interior advection).
+int exchange_inline(sfl_context *ctx, const std::vector<sfl_context *> &peers, int field, int rows, int skip = 0,
+                    hipEvent_t after = nullptr)
 {
     if (rows <= 0 || ctx->nranks == 1) return SFL_OK;
     if (!ctx->comm && !ctx->emulated) return exchange(peers, field, rows, nullptr, skip);
     Overlap o;
     SFL_TRY(overlap_of(ctx, &o));
-    SFL_TRY(start_exchange(peers, o, field, rows, skip));
+    if (after) {
+        SFL_TRY(use_device(peers[0]));
+        HIP_TRY(hipStreamWaitEvent(o.xstream, after, 0));
+        SFL_TRY(exchange(peers, field, rows, o.xstream, skip));
+        SFL_TRY(use_device(peers[0]));
+        HIP_TRY(hipEventRecord(o.arrived, o.xstream));
+    } else {
+        SFL_TRY(start_exchange(peers, o, field, rows, skip));
+    }
     return await_exchange(peers, o);
 }
 
@@ -1330,6 +1343,7 @@ int sfl_destroy(sfl_context *c)
     if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->ev_report) (void)hipEventDestroy(c->ev_report);
     if (c->ev_color_halo) (void)hipEventDestroy(c->ev_color_halo);
+    if (c->ev_vel_final) (void)hipEventDestroy(c->ev_vel_final);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->ev_arrived) (void)hipEventDestroy(c->ev_arrived);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -1847,8 +1861,8 @@ static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_conte
     }
     if (plan.gather)
         SFL_TRY(gather_field(ctx, peers, SFL_FIELD_VELOCITY));
-    else
-        SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, plan.halo));
+    else   // (with early rows in vel_tmp: the velocity was final before they were queued, the halo need not wait for them)
+        SFL_TRY(exchange_inline(ctx, peers, SFL_FIELD_VELOCITY, plan.halo, 0, interior_done > 0 ? ctx->ev_vel_final : nullptr));
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         const sfl::Slab whole{c->dim_x, c->gdim_y, 0, c->gdim_y};
@@ -2329,9 +2343,16 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
         c->last_early_kept = interior_done;
     }
     SFL_TRY(advect_velocity_planned(ctx, peers, dt, 1, pv, extend, interior_done));   // ino:252-256, exact halo
+    for (sfl_context *c : peers) SFL_TRY(apply_queued_forces(c));           // ino:264-269
+    SFL_TRY(sfl_calculate_divergence(ctx, dx));                             // ino:274
+    for (sfl_context *c : peers) c->solve_tail = 1;
+    const int rc_solve = sfl_poisson_solve(ctx, dx, iters, omega);          // ino:275
+    for (sfl_context *c : peers) c->solve_tail = 0;
+    SFL_TRY(rc_solve);
     // The dye is not touched before the end of the step and its halo is a guess made from what was known at the START of the
-    // step (the projection changes the velocity a little, forces may change it a lot: checked after the step): sent now, on
-    // the exchange stream, under the solve -- behind the velocity's halo and advection, which the step is waiting for.
+    // step (the projection changes the velocity a little, forces may change it a lot: checked after the step).  It is queued
+    // HERE, behind the solve's exchanges on the exchange stream and after everything the GPU is waiting for has been queued:
+    // the host needs 25 - 30 us for it, which used to stand between the velocity advection and the divergence.
     const int guess = std::min(limit, std::max(2, reach_v + 2 + reach_v / 4));
     {
         for (sfl_context *c : peers) {
@@ -2340,17 +2361,18 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
         }
         Overlap o;
         SFL_TRY(overlap_of(ctx, &o));
-        SFL_TRY(start_exchange(peers, o, SFL_FIELD_COLOR, guess, 0, false));
+        if (ctx->vel_final_recorded) {   // the dye has been final since the step began: nothing of this step to wait for
+            SFL_TRY(use_device(ctx));
+            HIP_TRY(hipStreamWaitEvent(o.xstream, ctx->ev_vel_final, 0));
+            SFL_TRY(exchange(peers, SFL_FIELD_COLOR, guess, o.xstream));
+        } else {
+            SFL_TRY(start_exchange(peers, o, SFL_FIELD_COLOR, guess, 0, false));
+        }
         SFL_TRY(use_device(ctx));
         HIP_TRY(hipEventRecord(ctx->ev_color_halo, o.xstream));
+        ctx->vel_final_recorded = false;
     }
-    for (sfl_context *c : peers) SFL_TRY(apply_queued_forces(c));           // ino:264-269
-    SFL_TRY(sfl_calculate_divergence(ctx, dx));                             // ino:274
-    for (sfl_context *c : peers) c->solve_tail = 1;
-    const int rc_solve = sfl_poisson_solve(ctx, dx, iters, omega);          // ino:275
-    for (sfl_context *c : peers) c->solve_tail = 0;
-    SFL_TRY(rc_solve);
-    // dye advection on the guessed halo sent at the start of the step
+    // dye advection on that guessed halo
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipMemsetAsync(c->d_report, 0, kReachWords * sizeof(int), c->stream));
@@ -2379,6 +2401,10 @@ static int advect_interior_early(sfl_context *ctx, float dt)
     const int limit = std::min(kGhostRows, min_owned_rows(ctx));
     for (sfl_context *c : peers)
         if (!c->vel || !c->vel_tmp || c->g1 - c->g0 < 2 * limit + 64) return SFL_OK;   // (nothing worth it, or not set up yet)
+    SFL_TRY(use_device(ctx));
+    if (!ctx->ev_vel_final) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_vel_final, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->ev_vel_final, ctx->stream));   // the velocity (and the dye) as the last step left them: what the halos will carry
+    ctx->vel_final_recorded = true;
     for (sfl_context *c : peers) {
         SFL_TRY(use_device(c));
         HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, c->g0 + limit, c->g1 - limit, c->g0,
