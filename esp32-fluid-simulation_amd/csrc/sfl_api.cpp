@@ -144,6 +144,7 @@ struct sfl_context {
     // land in pinned host memory behind ev_report, and are examined when the NEXT call touches the context
     int *d_report = nullptr;       // device reach words (launch_reach_set) with the flag in word [2]
     int *h_report = nullptr;       // pinned host copy
+    bool report_zeroed = false;    // d_report has been zeroed behind its copy to the host (post_reach_report)
     bool reach_in_report = false;  // the dye's kernel of this step has left the reach words in d_report already
     // slab_step_auto: the rows further than `early_rows` from both cuts were advected into vel_tmp BEFORE the host waited for the
     // last step's report (advect_interior_early); valid for the velocity of vel_epoch == early_epoch at early_dt
@@ -2252,6 +2253,8 @@ static int post_reach_report(sfl_context *ctx, const std::vector<sfl_context *> 
             SFL_TRY(use_device(c));
             HIP_TRY(hipMemcpyAsync(c->h_report, c->d_report, kReachWords * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->ev_report, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_report, 0, kReachWords * sizeof(int), c->stream));   // for the next step's dye kernel
+            c->report_zeroed = true;
         }
     }
     for (sfl_context *c : peers) {
@@ -2372,11 +2375,15 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
         HIP_TRY(hipEventRecord(ctx->ev_color_halo, o.xstream));
         ctx->vel_final_recorded = false;
     }
-    // dye advection on that guessed halo
+    // dye advection on that guessed halo.  Its report words are zero: where the last report was copied to the host on the compute
+    // stream they were zeroed right behind that copy (post_reach_report: the GPU is idle there and the host far ahead -- here the
+    // memset stood between the solve and the dye's kernel, at the start of the step it would stand in the host's way), else now
     for (sfl_context *c : peers) {
+        if (c->report_zeroed) continue;
         SFL_TRY(use_device(c));
         HIP_TRY(hipMemsetAsync(c->d_report, 0, kReachWords * sizeof(int), c->stream));
     }
+    for (sfl_context *c : peers) c->report_zeroed = false;
     if (ctx->opt_fuse_projection) {
         SFL_TRY(project_and_advect_color(ctx, dt, dx, guess, true, true));  // ino:276 + ino:281-287, one pass over v
     } else {
