@@ -111,13 +111,19 @@ template <bool NO_SLIP, bool SELF, int THREADS>
 __global__ void __launch_bounds__(THREADS)
 advect_vec2f_tiled_kernel(float2 *__restrict__ next_p, const float2 *p, const float2 *vel, Slab g, Slab gs,
                           TileGrid tg, int g_begin, int g_end, int valid_begin, int valid_end, float dt,
-                          int *halo_flag)
+                          int *halo_flag, int ny1, int g2_begin, int g2_end)
 {
     constexpr int kWaves = THREADS / 64, kRows = kTY / kWaves;
     constexpr int kLoads = (kSX * kSY + THREADS - 1) / THREADS;
     __shared__ float2 tile[kSY * kSX];
     int tx, ty;
     if (!tile_of_block(tg, tx, ty)) return;
+    // a launch covers up to two row ranges (the two bands of a slab next to its cuts in one launch: sfl_api.cpp
+    // advect_velocity_planned): the rows of tiles from ny1 on belong to [g2_begin, g2_end)
+    if (ty >= ny1) {
+        g_begin = g2_begin - ny1 * kTY;
+        g_end = g2_end;
+    }
     const int x0 = tx * kTX, y0 = g_begin + ty * kTY;
     const Window w = window_of<kR>(x0, y0, gs, valid_begin, valid_end);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -781,11 +787,12 @@ TileGrid tile_grid(int dim_x, int rows)
 
 hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *p, const float *vel, Slab g,
                                      int g_begin, int g_end, int valid_begin, int valid_end, float dt,
-                                     bool no_slip, int *halo_flag, const Slab *src)
+                                     bool no_slip, int *halo_flag, const Slab *src, int g2_begin, int g2_end)
 {
     if (g_end <= g_begin) return hipSuccess;
     const Slab gs = src ? *src : g;
-    const TileGrid tg = tile_grid(g.dim_x, g_end - g_begin);
+    const int ny1 = (g_end - g_begin + kTY - 1) / kTY, ny2 = g2_end > g2_begin ? (g2_end - g2_begin + kTY - 1) / kTY : 0;
+    const TileGrid tg = tile_grid(g.dim_x, (ny1 + ny2) * kTY);
     const dim3 grid(tg.per_xcd * kXcds), block(kThreadsVec2);
     auto *o = reinterpret_cast<float2 *>(next_p);
     auto *pi = reinterpret_cast<const float2 *>(p);
@@ -793,7 +800,7 @@ hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *
     const bool self = p == vel && !src;
 #define SFL_GO(NS_, SELF_)                                                                 \
     advect_vec2f_tiled_kernel<NS_, SELF_, kThreadsVec2><<<grid, block, 0, s>>>(            \
-        o, pi, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag)
+        o, pi, vi, g, gs, tg, g_begin, g_end, valid_begin, valid_end, dt, halo_flag, ny1, g2_begin, g2_end)
     if (no_slip) {
         if (self) { SFL_GO(true, true); } else { SFL_GO(true, false); }
     } else {

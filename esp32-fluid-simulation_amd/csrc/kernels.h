@@ -30,7 +30,8 @@ struct Slab {
 hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
                                Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
                                float dt, bool no_slip, int *halo_flag, const Slab *src = nullptr,
-                               int kernel = 0);
+                               int kernel = 0, int g2_begin = 0, int g2_end = 0);
+// (g2_begin < g2_end: a second range of output rows in the same launch -- the two bands of a slab next to its cuts)
 hipError_t launch_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const uint32_t *p,
                                   const float *vel, Slab g, int g_begin, int g_end,
                                   int valid_begin, int valid_end, float dt, bool no_slip,
@@ -57,7 +58,7 @@ hipError_t launch_project_advect_vec3uq32(hipStream_t s, uint32_t *next_p, const
 constexpr int kAdvectTiledMinCells = 16384;
 hipError_t launch_advect_vec2f_tiled(hipStream_t s, float *next_p, const float *p, const float *vel, Slab g,
                                      int g_begin, int g_end, int valid_begin, int valid_end, float dt,
-                                     bool no_slip, int *halo_flag, const Slab *src);
+                                     bool no_slip, int *halo_flag, const Slab *src, int g2_begin = 0, int g2_end = 0);
 // pressure != nullptr: the projection fused in (then src must be null)
 hipError_t launch_advect_vec3uq32_tiled(hipStream_t s, uint32_t *next_p, const uint32_t *p, float *vel,
                                         const float *pressure, Slab g, int g_begin, int g_end, int valid_begin,

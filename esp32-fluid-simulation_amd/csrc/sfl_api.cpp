@@ -1871,14 +1871,12 @@ static int advect_velocity_planned(sfl_context *ctx, const std::vector<sfl_conte
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, static_cast<const float *>(c->gather_buf),
                                              c->vel, c->geom, c->g0, c->g1, 0, c->gdim_y, dt, no_slip != 0,
                                              nullptr, &whole, c->opt_advect_kernel));
-        else if (interior_done > 0) {
-            for (int band = 0; band < 2; ++band)
-                HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom,
-                                                 band ? c->g1 - interior_done : clip_lo(c, c->g0 - extend),
-                                                 band ? clip_hi(c, c->g1 + extend) : c->g0 + interior_done,
-                                                 clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,
-                                                 no_slip != 0, advect_flag(c, plan), nullptr, c->opt_advect_kernel));
-        } else
+        else if (interior_done > 0)   // both bands in one launch
+            HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom, clip_lo(c, c->g0 - extend),
+                                             c->g0 + interior_done, clip_lo(c, c->g0 - plan.halo),
+                                             clip_hi(c, c->g1 + plan.halo), dt, no_slip != 0, advect_flag(c, plan), nullptr,
+                                             c->opt_advect_kernel, c->g1 - interior_done, clip_hi(c, c->g1 + extend)));
+        else
             HIP_TRY(sfl::launch_advect_vec2f(c->stream, c->vel_tmp, c->vel, c->vel, c->geom,
                                              clip_lo(c, c->g0 - extend), clip_hi(c, c->g1 + extend),
                                              clip_lo(c, c->g0 - plan.halo), clip_hi(c, c->g1 + plan.halo), dt,

@@ -323,12 +323,17 @@ hipError_t launch_backtrace_reach(hipStream_t s, int *reach, const float *vel, S
 
 hipError_t launch_advect_vec2f(hipStream_t s, float *next_p, const float *p, const float *vel,
                                Slab g, int g_begin, int g_end, int valid_begin, int valid_end,
-                               float dt, bool no_slip, int *halo_flag, const Slab *src, int kernel)
+                               float dt, bool no_slip, int *halo_flag, const Slab *src, int kernel, int g2_begin, int g2_end)
 {
     if (g_end <= g_begin) return hipSuccess;
     if (use_tiled_advect(kernel, g, g_begin, g_end))
         return launch_advect_vec2f_tiled(s, next_p, p, vel, g, g_begin, g_end, valid_begin, valid_end, dt,
-                                         no_slip, halo_flag, src);
+                                         no_slip, halo_flag, src, g2_begin, g2_end);
+    if (g2_end > g2_begin) {   // the one-thread-per-cell kernel: one launch per range
+        const hipError_t e = launch_advect_vec2f(s, next_p, p, vel, g, g2_begin, g2_end, valid_begin, valid_end, dt, no_slip,
+                                                 halo_flag, src, kernel);
+        if (e != hipSuccess) return e;
+    }
     const Slab gs = src ? *src : g;
     SFL_ADV_GRID(g.dim_x, g_end - g_begin);
     auto *o = reinterpret_cast<float2 *>(next_p);
