@@ -264,6 +264,9 @@ def pmc_record(grid, fuse, world):
     return best, bool(best) and best.get("kernel_source_sha16") == kernel_source_hash()
 
 
+SCHEDULES = {0: "none", 1: "in line", 2: "one launch early, behind events", 3: "in time, counted on the device"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +299,11 @@ def parse_args(argv=None):
                          "ms per solve of that rank = the per-GPU critical path without the wire; results next to "
                          "the cuts are meaningless, so parity and the CPU baseline are skipped")
     ap.add_argument("--of", type=int, default=8, help="group size for --emulate-rank")
+    ap.add_argument("--via-rccl", action="store_true",
+                    help="--emulate-rank: every halo message is a real ncclSend / ncclRecv of the rank to ITSELF on a one-rank "
+                         "communicator, issued through the code path a real rank takes, and the step's reductions are "
+                         "ncclAllReduce on it (sfl_comm_emulate_rccl): RCCL's own kernels beside the solve's launches")
+    ap.add_argument("--halo-timeout-ms", type=int, default=0, help="SFL_OPT_HALO_TIMEOUT_MS (0 = the transport's default)")
     ap.add_argument("--wire-us", type=int, default=0,
                     help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
@@ -307,6 +315,9 @@ def parse_args(argv=None):
     ap.add_argument("--arrival-by-event", action="store_true",
                     help="SFL_OPT_SOR_ARRIVAL = 0: early halo exchanges behind cross-stream events (round 3's scheme) instead of "
                          "in-time exchanges counted on the device (A/B)")
+    ap.add_argument("--arrival-in-time", action="store_true",
+                    help="SFL_OPT_SOR_ARRIVAL = 1: exchanges in time, counted on the device, also where the library would not "
+                         "choose them by itself (RCCL ranks whose peers are other processes)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
     ap.add_argument("--dry-run", action="store_true",
@@ -440,7 +451,17 @@ def run_rank(args):
         if world != 1:
             sys.exit("--emulate-rank runs on ONE GPU")
         s = sfl.Solver(size, dim_y, device=local_rank, rank=args.emulate_rank, nranks=args.of)
-        s.comm_emulate()
+        if args.via_rccl:
+            sys.stdout.flush()          # (RCCL's banner goes to stdout: keep it off the JSON line)
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                s.comm_emulate_rccl()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            s.comm_emulate()
         if args.wire_us:
             s.set_option(capi.OPT_EMULATE_WIRE_US, args.wire_us)
         args.no_cpu_baseline = True
@@ -450,6 +471,10 @@ def run_rank(args):
         s.set_option(capi.OPT_SOR_OVERLAP, 0)
     if args.arrival_by_event:
         s.set_option(capi.OPT_SOR_ARRIVAL, 0)
+    if args.arrival_in_time:
+        s.set_option(capi.OPT_SOR_ARRIVAL, 1)
+    if args.halo_timeout_ms:
+        s.set_option(capi.OPT_HALO_TIMEOUT_MS, args.halo_timeout_ms)
     if args.chain is not None:
         s.set_option(capi.OPT_SOR_CHAIN, args.chain)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
@@ -521,6 +546,7 @@ def run_rank(args):
             s.poisson_solve(1.0, iters, omega)
     elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
+    schedule = s.get_option(capi.OPT_EXCHANGE_SCHEDULE)
     try:
         info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
     except sfl.SflError:                                        # (an older library under tools/with_lib.py)
@@ -679,7 +705,8 @@ def run_rank(args):
             "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
             "supersteps_in_chained_launches": info["chained"],
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
-            "emulated_wire_us": args.wire_us,
+            "emulated_wire_us": args.wire_us, "transport": "rccl-to-self" if args.via_rccl else "copy-kernel",
+            "exchange_schedule": SCHEDULES.get(schedule, schedule),
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None, **({"sim_steps_note": sim_note} if sim_note else {}),
             "note": "one rank's program alone on one GPU, halo messages as self-copies of the same size on the "
                     "exchange stream (sfl_comm_emulate); values next to the cuts are meaningless",
@@ -763,6 +790,7 @@ def run_rank(args):
                        "sor_launches_per_solve": info["launches"],
                        "supersteps_in_chained_launches": info["chained"],
                        "halo_exchanges_per_solve": info["exchanges"],
+                       "exchange_schedule": SCHEDULES.get(schedule, schedule),
                        "half_sweeps_fused_per_launch": info["fuse"]},
             "parity": parity,
             **({"sim_step_parity": step_parity} if step_parity is not None else {}),

@@ -24,6 +24,8 @@ OPT_STEP_SEAMS = 14
 OPT_SOR_CHAIN = 15
 OPT_LAST_CHAINED = 16
 OPT_LAST_EARLY_ROWS = 17
+OPT_HALO_TIMEOUT_MS = 18
+OPT_EXCHANGE_SCHEDULE = 19
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128
@@ -108,6 +110,7 @@ SIGNATURES = {
     "sfl_comm_check_options": (_i, [_ctx]),
     "sfl_comm_loopback": (_i, [_ctx, _i]),
     "sfl_comm_emulate": (_i, [_ctx]),
+    "sfl_comm_emulate_rccl": (_i, [_ctx]),
     "sfl_group_link": (_i, [C.POINTER(_ctx), _i]),
     "sfl_upload": (_i, [_ctx, _i, C.c_void_p, _sz]),
     "sfl_download": (_i, [_ctx, _i, C.c_void_p, _sz]),

@@ -126,7 +126,7 @@ struct SorRows {
 // input rows all lie inside [own_lo, own_hi) -- rows no message writes -- run at once, the others (the tiles next
 // to a cut) first wait, inside the launch, until *flag has reached `epoch` (signed distance: the word only
 // counts up, launch_signal_arrival), then make the arrived rows visible to their CU (agent-scope acquire).  A wait
-// that lasts longer than kHaloWaitTimeoutUs gives up and raises *timed_out (results are then wrong: the host turns
+// that lasts longer than HaloWait::timeout_us gives up and raises *timed_out (results are then wrong: the host turns
 // the word into an error): a lost message must never hang the GPU.  flag == nullptr: nobody waits.
 //
 // The other direction, in the same struct: `done` != nullptr makes the tiles whose output rows reach below send_lo_end or
@@ -141,8 +141,11 @@ struct HaloWait {
     int own_lo, own_hi;
     int *done;
     int send_lo_end, send_hi_begin;
+    int timeout_us;     // how long a wait may last before it gives up (0: kHaloWaitDefaultTimeoutUs).  Ranks whose peers are
+                        // other processes pass minutes: a peer's host may simply be late (Transport::default_timeout_us)
+    int system_scope;   // != 0: the arrived rows were written by ANOTHER GPU (RCCL over xGMI): system-scope acquire
 };
-constexpr int kHaloWaitTimeoutUs = 2000000;
+constexpr int kHaloWaitDefaultTimeoutUs = 2000000;
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait = nullptr,
@@ -157,7 +160,7 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
 // and writes the other.  steps[i].hw carries the halo protocol of that superstep exactly as for launch_sor_fused (arrival to wait
 // for, sender tiles to count); senders[i] receives the number of its sender tiles.  `max_waves` bounds the waves of the launch
 // (0: what is resident on the device at once) -- every wave must be resident for the chain to make progress, so callers that
-// run other work beside it leave room.  A wait of more than kHaloWaitTimeoutUs raises *timed_out.  Requires what the 8-byte
+// run other work beside it leave room.  A wait of more than steps[0].hw.timeout_us raises *timed_out.  Requires what the 8-byte
 // path requires (even dim_x, 8-byte aligned arrays) and a fuse depth in {8, 10, 12, 16}: sor_chain_supported.
 constexpr int kMaxChain = 16;
 struct ChainStep {
@@ -181,8 +184,9 @@ hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d,
 // *flag = value, visible to every CU (stream-ordered behind the message / the kernels that relaxed it)
 hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value);
 // One wave that returns when *count has reached `target` (signed distance; sender tiles of launches on ANOTHER stream
-// count it up) or after kHaloWaitTimeoutUs, raising *timed_out: what follows on the stream starts then.
-hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out);
+// count it up) or after `timeout_us`, raising *timed_out: what follows on the stream starts then.
+hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out,
+                             int timeout_us = kHaloWaitDefaultTimeoutUs);
 
 // ---- small grids: one workgroup, fields in LDS (small_grid.hip) -------------------------------------
 // WHOLE-DOMAIN arrays of dim_x * dim_y <= kSmallGridMaxCells cells (16 B of LDS per cell: 96 KB of the CU's 160;

@@ -1,0 +1,545 @@
+// sor_executor.cpp -- poisson_solve (poisson.cpp:114-125) on a context: walks the launch / exchange program of
+// slab_plan.h.  Three schedules for the halo exchanges of a slab (all the same bits):
+//   in line            every launch whole, every exchange awaited (SFL_OPT_SOR_OVERLAP = 0, the baseline kernel)
+//   early, by events   the halo of a superstep travels one launch early on the exchange stream, its ghost rows are
+//                      relaxed behind the message, the launch after waits for an event (SFL_OPT_SOR_ARRIVAL = 0)
+//   in time, counted   the halo follows the launch that produces it; sender tiles count themselves, the message leaves
+//                      on that count, only the next launch's cut-adjacent tiles wait -- inside the kernel -- for a
+//                      count of arrivals (SFL_OPT_SOR_ARRIVAL = 1; optionally as chained launches, SFL_OPT_SOR_CHAIN)
+// Host C++ only; the kernels live in sor_fused.hip / stencil_kernels.hip / small_grid.hip.
+#include "transport.h"
+
+namespace sfl {
+namespace host {
+
+sfl::SorParams sor_params(float dx, float omega)
+{
+    sfl::SorParams prm;
+    prm.dx = dx;
+    prm.omega = omega;
+    prm.one_minus_omega = 1.0f - omega;  // (1 - omega) in float, poisson.cpp:98,111
+    return prm;
+}
+
+// Fuse depth: explicit option, or auto from the slab size.  Measured on MI355X, ms per 80-iteration
+// solve at fuse 8 / 10 / 12 / 14 / 16 (round 2, gpurun_out/r02_run13-14, auto rows per tile):
+// 8192 x 8192: 3.6 / 3.0 / 2.51 / 2.39 / 1.95; 8192 x 4096: - / - / 1.26 / 1.14 / 1.08; 8192 x 2048: - / 0.70 /
+// 0.64 / 0.60 / 0.60; 8192 x 1024: 0.458 / 0.398 / 0.425 / 0.57 / 0.64; 8192 x 512 (round 1): 0.39 / - / 0.42 /
+// - / 0.45; 40 iterations: 4096^2 - / 0.343 / 0.327 / 0.308 / 0.294; 3072^2 0.245 / 0.208 / 0.223 / 0.294 / 0.297; 2048^2
+// 0.155 / 0.143 / 0.175 / - / 0.217; 1024^2 0.086 / 0.090 / 0.097; 8192 x 768 (80): 0.366 / 0.333 / 0.393; 8192 x 512: 0.303 /
+// 0.305 / 0.350.  Big slabs are bound by the pass over memory
+// each launch makes and want the deepest fusion; small ones by the 2 * NS warm-up rows each tile
+// re-streams.  Every rank of a group sees the same thinnest slab, so all ranks resolve the same value.
+int effective_fuse(const sfl_context *c)
+{
+    int f = c->opt_sor_fuse;
+    if (f == 0) {
+        const int64_t cells = (int64_t)min_owned_rows(c) * c->dim_x;
+        f = cells >= 12000000 ? 16 : cells >= 3000000 ? 10 : 8;
+    }
+    if (f < 2) f = 2;
+    if (f > SFL_MAX_FUSE) f = SFL_MAX_FUSE;
+    return f & ~1;
+}
+
+int effective_kernel(const sfl_context *c) { return c->opt_sor_kernel == 1 ? 1 : 2; }
+
+// One workgroup, fields in LDS (small_grid.hip): whole-domain contexts of at most kSmallGridMaxCells cells whose
+// kernel options are all automatic (an explicit kernel / fuse / tile choice is honoured as given).
+bool small_grid(const sfl_context *c)
+{
+    return c->opt_small_grid && c->nranks == 1 && !c->transport &&
+           sfl::small_grid_fits(c->dim_x, c->gdim_y) && c->opt_sor_kernel == 0 &&
+           c->opt_sor_fuse == 0 && c->opt_sor_rows == 0 && c->opt_sor_lane_cells == 0 && c->opt_advect_kernel == 0;
+}
+
+
+int effective_halo(const sfl_context *c, int fuse)
+{
+    // auto: 64 rows on slabs of >= 1024 rows (2-3 exchanges per 80-iteration solve, ~5 % extra
+    // rows recomputed), 32 on thinner ones
+    int h = c->opt_sor_halo ? c->opt_sor_halo : (min_owned_rows(c) >= 1024 ? 64 : 32);
+    if (h > min_owned_rows(c)) h = min_owned_rows(c);  // a neighbour can only send rows it owns
+    if (h > kGhostRows) h = kGhostRows;
+    return h < fuse ? fuse : h;
+}
+
+// Exchanges IN TIME with everything counted on the device (run_poisson_in_time; SFL_OPT_SOR_ARRIVAL) instead of early exchanges
+// behind cross-stream events: slabs with a transport, the fused kernel, exchanges overlapped -- where the transport takes it by
+// default (Transport::arrival_by_default) or the option asks for it, and only where the compute and the exchange stream were
+// seen to run side by side (resolve_schedule: a launch that waits inside the kernel must not sit in front of its message).
+bool in_time_exchanges(const sfl_context *c)
+{
+    if (!c->transport || !c->opt_sor_overlap || c->nranks < 2 || c->opt_sor_kernel == 1) return false;
+    const int asked = c->opt_sor_arrival >= 0 ? c->opt_sor_arrival : (c->transport->arrival_by_default() ? 1 : 0);
+    const int side_by_side = c->group ? c->group->streams_concurrent : c->streams_concurrent;
+    return asked && side_by_side == 1;
+}
+
+// The one thing in_time_exchanges cannot find out as a const query: do the two streams run side by side?  Measured once
+// (transport.cpp streams_run_concurrently); ranks of a communicator measured it at attach and agreed on the result.
+int resolve_schedule(sfl_context *ctx)
+{
+    if (!ctx->transport || ctx->nranks < 2) return SFL_OK;
+    bool yes = false;
+    return streams_run_concurrently(ctx, &yes);
+}
+
+int halo_timeout_us(const sfl_context *c)
+{
+    if (c->opt_halo_timeout_ms > 0) return c->opt_halo_timeout_ms > 2000000 ? 2000000000 : c->opt_halo_timeout_ms * 1000;
+    return c->transport ? c->transport->default_timeout_us() : 2000000;
+}
+
+// ---- poisson_solve executor --------------------------------------------------------------
+// One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
+// all pieces read c->p and write c->p_alt; the caller swaps once per step).
+// `in` / `out` = the step's input and output arrays (null: c->p / c->p_alt); `on` = stream (null: the compute stream)
+int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
+                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const float *in = nullptr,
+                    float *out = nullptr, const sfl::HaloWait *wait = nullptr, int *senders = nullptr)
+{
+    if (senders) *senders = 0;
+    if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
+    if (!in) in = c->p;
+    if (!out) out = c->p_alt;
+    SFL_TRY(use_device(c));
+    // Slabs that outgrow the Infinity Cache (256 MB; p + d of 48 M cells = 384 MB) reverse the stream direction of
+    // every tile from one launch to the next: a launch then begins on the rows its predecessor read and wrote
+    // last, the only ones still cached (8192^2: -3 % per launch; no gain or a small loss on slabs that fit:
+    // profiles/r03_alternate_sweep.txt).  last_launches counts the plan steps issued so far in this solve.
+    const int sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches : 0;
+    HIP_TRY(sfl::launch_sor_fused(on ? on : c->stream, out, st.from_zero ? nullptr : in, c->div, c->geom,
+                                  sfl::SorRows{g_begin, g_end, g2_begin, g2_end}, st.nsweeps, st.first_colour,
+                                  prm, c->opt_sor_rows, sweep, wait, senders));
+    return SFL_OK;
+}
+
+// Device-side halo arrival (run_poisson_in_time, kernels.h HaloWait).  The exchange stream counts a context's arrived
+// messages in a device word; the next launch on the compute stream is queued WITHOUT a cross-stream event and lets only
+// its cut-adjacent tiles wait for the count.
+sfl::HaloWait arrival_wait(const sfl_context *c)
+{
+    sfl::HaloWait w;
+    w.flag = c->d_arrival;
+    w.timed_out = c->d_arrival + 1;
+    w.epoch = c->arrival_epoch;
+    w.own_lo = c->rank > 0 ? c->g0 : -(1 << 30);                 // no cut on that side: nothing to wait for
+    w.own_hi = c->rank < c->nranks - 1 ? c->g1 : (1 << 30);
+    w.done = nullptr;
+    w.send_lo_end = w.send_hi_begin = 0;
+    w.timeout_us = halo_timeout_us(c);
+    w.system_scope = c->transport && c->transport->separate_processes();   // the halo rows were written by another GPU
+    return w;
+}
+
+int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm)
+{
+    SFL_TRY(use_device(c));
+    if (st.kind == SFL_STEP_ZERO) {
+        HIP_TRY(sfl::launch_zero_rows(c->stream, c->p, c->geom, clip_lo(c, c->geom.grow0),
+                                      clip_hi(c, c->geom.grow0 + c->geom.lrows)));
+        ++c->last_launches;
+        return SFL_OK;
+    }
+    if (st.nsweeps == 1) {
+        HIP_TRY(sfl::launch_sor_half_sweep(c->stream, c->p, c->div, c->geom, st.g_begin, st.g_end,
+                                           st.first_colour, prm));
+        ++c->last_launches;
+        return SFL_OK;
+    }
+    SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end));
+    std::swap(c->p, c->p_alt);
+    ++c->last_launches;  // plan steps, not pieces: an overlapped step counts once as well
+    return SFL_OK;
+}
+
+// ---- chained supersteps (kernels.h launch_sor_chain; SFL_OPT_SOR_CHAIN) ---------------------------------------------------
+// May plan steps [i, i + n) of `prog` go into one chained launch?  SOR steps of one supported fuse depth, none from zero.
+int chainable_steps(const sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, bool across_exchanges)
+{
+    if (c->opt_sor_chain <= 0 || effective_kernel(c) != 2) return 0;   // (automatic: only where exchanges run in time, below)
+    int n = 0;
+    size_t k = i;
+    for (; k < prog.size() && n < sfl::kMaxChain; ++k) {
+        const sfl_plan_step &st = prog[k];
+        if (st.kind == SFL_STEP_EXCHANGE && across_exchanges && st.field == SFL_FIELD_PRESSURE && n > 0) continue;
+        if (st.kind != SFL_STEP_SOR || st.from_zero || st.first_colour != 0 || st.nsweeps != prog[i].nsweeps ||
+            st.g_end <= st.g_begin)
+            break;
+        ++n;
+    }
+    if (n < 2 || !sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, prog[i].nsweeps)) return 0;
+    return n;
+}
+
+int ensure_chain_words(sfl_context *c)
+{
+    if (c->d_chain) return SFL_OK;
+    // more words than any tiling of the slab has tiles: strips of >= 96 kept columns x chunks of >= kMinEdgeRows rows
+    const int words = 32 * (c->dim_x / 96 + 3) * (c->geom.lrows / 8 + 4);   // a 128-byte line per tile
+    void *m = nullptr;
+    SFL_TRY(use_device(c));
+    HIP_TRY(hipMalloc(&m, (size_t)words * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(m, 0, (size_t)words * sizeof(int), c->stream));
+    c->d_chain = static_cast<int *>(m);
+    c->chain_words = words;
+    return SFL_OK;
+}
+
+// Plan steps [i, i + n) of a context whose launches need no halo protocol (whole domains, the in-line order), as one launch.
+int exec_sor_chain(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, int n, const sfl::SorParams &prm)
+{
+    SFL_TRY(ensure_chain_words(c));
+    sfl::ChainStep steps[sfl::kMaxChain];
+    for (int k = 0; k < n; ++k) {
+        const sfl_plan_step &st = prog[i + k];
+        steps[k].g_begin = st.g_begin;
+        steps[k].g_end = st.g_end;
+        steps[k].sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + k : 0;
+        steps[k].hw = sfl::HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0};
+        steps[k].guard_flag = nullptr;
+        steps[k].guard_epoch = steps[k].guard_lo_end = steps[k].guard_hi_begin = 0;
+    }
+    HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, prog[i].nsweeps, prm, c->opt_sor_rows,
+                                  c->d_chain, c->chain_words, c->chain_epoch, c->d_arrival + 1,
+                                  c->opt_sor_chain >= 8 ? c->opt_sor_chain & ~3 : 0, nullptr));
+    c->chain_epoch += n + 1;
+    if (n & 1) std::swap(c->p, c->p_alt);
+    c->last_launches += n;
+    c->last_chained += n;
+    return SFL_OK;
+}
+// The rows the last p halo message of a solve was read from, and how many supersteps have been issued since: the superstep
+// two behind a message overwrites its source (kernels.h ChainStep::guard_flag).
+struct SentBand {
+    bool valid = false;
+    int epoch = 0, lo_end = 0, hi_begin = 0, age = 0;
+};
+
+// In-time exchanges with the launches CHAINED (SFL_OPT_SOR_CHAIN): the SOR steps from step i on -- up to kMaxChain, p exchanges
+// between and behind them included -- as one chained launch per context, with the exchange stream's work (wait for the sender
+// counts, copy / send, raise the arrival counts) queued behind them exactly as for single launches.  The chains of the virtual
+// ranks of a group wait for each other's messages, so they must RUN side by side: the first on the compute stream, the others
+// on a stream of their own each (joined back into the compute stream), all of them within a budget of waves that is resident
+// at once.  *next = first plan step not consumed (== i: nothing was chained).
+int chain_in_time(const std::vector<sfl_context *> &peers, const std::vector<std::vector<sfl_plan_step>> &progs, size_t i,
+                  const sfl::SorParams &prm, const Overlap &o, bool *flagged, std::vector<SentBand> *bands, size_t *next)
+{
+    *next = i;
+    const std::vector<sfl_plan_step> &prog = progs[0];   // every rank's program has the same shape
+    std::vector<size_t> sor;
+    std::vector<long> xch;   // the p exchange behind sor[k] (index into prog), or -1
+    size_t k = i;
+    const int ns = prog[i].nsweeps;
+    while (k < prog.size() && (int)sor.size() < sfl::kMaxChain) {
+        bool ok = true;
+        for (size_t r = 0; r < peers.size(); ++r) {
+            const sfl_plan_step &st = progs[r][k];
+            ok = ok && st.kind == SFL_STEP_SOR && !st.from_zero && st.first_colour == 0 && st.nsweeps == ns && st.g_end > st.g_begin;
+        }
+        if (!ok) break;
+        sor.push_back(k++);
+        if (k < prog.size() && prog[k].kind == SFL_STEP_EXCHANGE && prog[k].field == SFL_FIELD_PRESSURE)
+            xch.push_back((long)k++);
+        else
+            xch.push_back(-1);
+    }
+    const int n = (int)sor.size();
+    if (n < 2) return SFL_OK;
+    for (sfl_context *c : peers)
+        if (!sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, ns)) return SFL_OK;
+    // two waves per SIMD for all chains together: room for the exchange stream's kernels beside them, and the occupancy the
+    // chain runs best at -- a thin slab's tiling has two tiles per SIMD; the slabs that touch the domain's boundary have three,
+    // and their chains do better with two waves per SIMD that take a second tile (0.398 ms) than with three (0.444)
+    int dev = 0, cus = 256;
+    SFL_TRY(use_device(peers[0]));
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int budget = cus * 8 / (int)peers.size();
+    if (peers[0]->opt_sor_chain >= 8 && peers[0]->opt_sor_chain < budget) budget = peers[0]->opt_sor_chain;
+    budget -= budget % 4;
+    // Side by side means a hardware queue each, for the compute stream, the exchange stream and every side stream; the runtime
+    // folds its streams onto GPU_MAX_HW_QUEUES (default 4) of them in turn.  Two virtual ranks fit the default; three when the
+    // process was started with more queues (tests/conftest.py does).  Folded streams are not a hang but a reported time-out.
+    static const int side_chains = [] {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        return q && atoi(q) >= 6 ? Group::kSideChains : 1;
+    }();
+    if (budget < 8 || (int)peers.size() > 1 + side_chains || (peers.size() > 1 && !peers[0]->group)) return SFL_OK;
+    for (sfl_context *c : peers) SFL_TRY(ensure_chain_words(c));   // (zeroed on the compute stream: before the event below)
+    if (peers.size() > 1) HIP_TRY(hipEventRecord(o.ready, o.compute));   // the side streams start behind what is queued so far
+
+    std::vector<std::vector<int>> senders(peers.size(), std::vector<int>(sfl::kMaxChain, 0));
+    bool fl_out = *flagged;
+    for (size_t r = 0; r < peers.size(); ++r) {
+        sfl_context *c = peers[r];
+        sfl::ChainStep steps[sfl::kMaxChain];
+        int epoch = c->arrival_epoch;   // the value the arrival count reaches with the exchanges issued so far
+        bool fl = *flagged;
+        SentBand b = (*bands)[r];
+        for (int q = 0; q < n; ++q) {
+            const sfl_plan_step &st = progs[r][sor[q]];
+            sfl::ChainStep &cs = steps[q];
+            cs.g_begin = st.g_begin;
+            cs.g_end = st.g_end;
+            cs.sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + q : 0;
+            cs.hw = arrival_wait(c);
+            cs.hw.epoch = epoch;
+            if (!fl) cs.hw.flag = nullptr;
+            ++b.age;
+            cs.guard_flag = b.valid && b.age == 2 ? c->d_arrival : nullptr;
+            cs.guard_epoch = b.epoch;
+            cs.guard_lo_end = b.lo_end;
+            cs.guard_hi_begin = b.hi_begin;
+            fl = false;
+            if (xch[q] >= 0) {
+                const sfl_plan_step &x = progs[r][xch[q]];
+                cs.hw.done = c->d_done;
+                cs.hw.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                cs.hw.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+                ++epoch;
+                fl = true;
+                b.valid = true;
+                b.epoch = epoch;
+                b.lo_end = cs.hw.send_lo_end;
+                b.hi_begin = cs.hw.send_hi_begin;
+                b.age = 0;
+            }
+        }
+        hipStream_t on = c->stream;
+        if (r > 0) {
+            on = c->group->chain_stream[r - 1];
+            HIP_TRY(hipStreamWaitEvent(on, o.ready, 0));
+        }
+        bool launched = false;
+        HIP_TRY(sfl::launch_sor_chain(on, c->p, c->p_alt, c->div, c->geom, steps, n, ns, prm, c->opt_sor_rows, c->d_chain,
+                                      c->chain_words, c->chain_epoch, c->d_arrival + 1, budget, senders[r].data(),
+                                      c->opt_sor_chain < 0 ? cus * 13 : 0, &launched));
+        if (!launched) return SFL_OK;   // (automatic mode: thin slabs only; first context: nothing has been changed yet)
+        if (r > 0) HIP_TRY(hipEventRecord(c->group->ev_chain[r - 1], on));
+        c->chain_epoch += n + 1;
+        c->last_launches += n;
+        c->last_chained += n;
+        (*bands)[r] = b;
+        fl_out = fl;
+    }
+    for (size_t r = 1; r < peers.size(); ++r) HIP_TRY(hipStreamWaitEvent(o.compute, peers[r]->group->ev_chain[r - 1], 0));
+    for (int q = 0; q < n; ++q) {
+        for (sfl_context *c : peers) std::swap(c->p, c->p_alt);   // c->p = what superstep q writes: the message's source
+        for (size_t r = 0; r < peers.size(); ++r) peers[r]->done_target += senders[r][q];
+        if (xch[q] < 0) continue;
+        const sfl_plan_step &x = prog[xch[q]];
+        SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
+    }
+    *flagged = fl_out;
+    *next = k;
+    return SFL_OK;
+}
+
+// Exchanges IN TIME (slab_plan.cpp kernel 3; SFL_OPT_SOR_ARRIVAL): the halo of a superstep is sent after the launch that
+// produces it, as in the textbook -- but nothing waits for a whole launch any more.  The launch in front of an exchange
+// marks the tiles whose rows the message carries as SENDERS (top priority; each counts itself once its rows are written
+// back); the exchange stream waits for that count, not for the launch, so the message leaves while the rest of the launch
+// is still running; the launch behind the exchange is queued at once and only its cut-adjacent tiles wait for the arrival
+// count.  No event on the compute stream, no ghost launch, no launch split.  (The right-hand side at the head of a solve
+// was produced by other kernels: its exchange still starts behind an event.)
+int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                        const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
+{
+    bool flagged = false;   // the next launch's cut-adjacent tiles wait for the arrival count
+    std::vector<SentBand> bands(peers.size());   // the last p message's source rows, per context (chained launches)
+    bool chain_refused = false;
+    const size_t n = progs[0].size();
+    for (size_t i = 0; i < n; ++i) {
+        const sfl_plan_step &st0 = progs[0][i];
+        if (st0.kind == SFL_STEP_EXCHANGE) {   // the right-hand side (a p exchange is taken together with the launch before it)
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin, false, true));
+            flagged = true;
+            continue;
+        }
+        // automatic (-1): a context with a transport of its own (RCCL, the emulated rank) on slabs thin enough that every tile is
+        // resident at two waves per SIMD; virtual ranks (a test transport) only when asked to
+        if ((ctx->opt_sor_chain > 0 || (ctx->opt_sor_chain < 0 && !ctx->group && !chain_refused)) && !st0.from_zero) {
+            size_t next = i;
+            SFL_TRY(chain_in_time(peers, progs, i, prm, o, &flagged, &bands, &next));
+            if (next > i) {
+                i = next - 1;
+                continue;
+            }
+            chain_refused = true;   // decided once per solve: the first attempt holds the widest row ranges
+        }
+        for (SentBand &b : bands) ++b.age;
+        const bool sends = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE && progs[0][i + 1].field == SFL_FIELD_PRESSURE;
+        for (size_t k = 0; k < peers.size(); ++k) {
+            sfl_context *c = peers[k];
+            const sfl_plan_step &st = progs[k][i];
+            sfl::HaloWait w = arrival_wait(c);
+            if (!flagged) w.flag = nullptr;
+            if (sends) {
+                const sfl_plan_step &x = progs[k][i + 1];
+                w.done = c->d_done;
+                w.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                w.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+            }
+            int senders = 0;
+            SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr, nullptr, nullptr,
+                                    (flagged || sends) ? &w : nullptr, &senders));
+            c->done_target += senders;
+            std::swap(c->p, c->p_alt);
+            ++c->last_launches;
+        }
+        flagged = false;
+        if (sends) {
+            const sfl_plan_step &x = progs[0][i + 1];
+            SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
+            flagged = true;
+            for (size_t k = 0; k < peers.size(); ++k) {
+                const sfl_context *c = peers[k];
+                bands[k].valid = true;
+                bands[k].epoch = c->arrival_epoch;
+                bands[k].lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
+                bands[k].hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
+                bands[k].age = 0;
+            }
+            ++i;   // the exchange step has been issued
+        }
+    }
+    return SFL_OK;
+}
+
+// EARLY exchanges behind cross-stream events (slab_plan.cpp kernel 2 with halo >= 2 x fuse: every automatic
+// configuration; SFL_OPT_SOR_ARRIVAL = 0, and the default of a transport whose peers are other processes).  The ghost rows
+// are still valid as deep as the next launch needs for the OWNED rows when the halo of the following superstep is sent:
+//   compute stream    that launch, owned rows only, whole -- no piece of it waits for the wire;
+//   exchange stream   the message (rows beyond that depth), then the same launch's passes on the ghost rows it feeds
+//                     (output rows [g_begin, g0) and [g1, g_end)).  Both read p and write p_alt, on disjoint rows; the
+//                     message lands in rows of p that the owned-row launch reads only into its throw-away rim;
+//   the launch AFTER  waits for `arrived` -- WHOLE: it overwrites the owned rows this rank's own outgoing message is
+//                     still being read from (round 4 let only its cut-adjacent tiles wait, on a device-side count: one
+//                     solve in 26 000 came out wrong, profiles/r04_exchanges_counted_on_the_device.txt).
+// Every other exchange of the program (the right-hand side at the head of a solve; p at halo < 2 x fuse) is awaited in
+// line: round 2's split launches around them (cut-adjacent rows first / last) are gone -- one more executor that had to
+// stay bit-exact for 16 us per solve.  The same bits as the in-line order.
+int run_poisson_early(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                      const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
+{
+    bool pending = false;  // an early exchange is in flight, with the ghost rows relaxed behind it: the next launch needs all of it
+    const size_t n = progs[0].size();
+    for (size_t i = 0; i < n; ++i) {
+        const sfl_plan_step &st0 = progs[0][i];
+        if (pending) {
+            SFL_TRY(await_exchange(peers, o));
+            pending = false;
+        }
+        if (st0.kind == SFL_STEP_EXCHANGE && st0.field == SFL_FIELD_PRESSURE && st0.g_begin > 0 && i + 1 < n &&
+            progs[0][i + 1].kind == SFL_STEP_SOR && progs[0][i + 1].nsweeps <= st0.g_begin) {
+            SFL_TRY(start_exchange(peers, o, SFL_FIELD_PRESSURE, st0.rows, st0.g_begin, false));
+            for (size_t k = 0; k < peers.size(); ++k) {
+                sfl_context *c = peers[k];
+                const sfl_plan_step &st = progs[k][i + 1];
+                const int lo = c->rank > 0 ? c->g0 : st.g_begin;
+                const int hi = c->rank < c->nranks - 1 ? c->g1 : st.g_end;
+                SFL_TRY(launch_sor_rows(c, st, prm, lo, hi));                                      // compute stream
+                SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, lo, hi, st.g_end, o.xstream));     // behind the message
+            }
+            SFL_TRY(mark_arrived(peers, o));
+            for (sfl_context *c : peers) {
+                std::swap(c->p, c->p_alt);
+                ++c->last_launches;
+            }
+            pending = true;
+            ++i;  // the launch has been issued
+            continue;
+        }
+        if (st0.kind == SFL_STEP_EXCHANGE) {
+            SFL_TRY(start_exchange(peers, o, st0.field, st0.rows, st0.g_begin));
+            SFL_TRY(await_exchange(peers, o));
+            continue;
+        }
+        for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+    }
+    if (pending) SFL_TRY(await_exchange(peers, o));
+    return SFL_OK;
+}
+
+int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &peers,
+                           const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm)
+{
+    Overlap o;
+    SFL_TRY(overlap_of(ctx, &o));
+    const int rc = in_time_exchanges(ctx) ? run_poisson_in_time(ctx, peers, progs, prm, o)
+                                          : run_poisson_early(ctx, peers, progs, prm, o);
+    if (rc != SFL_OK) {
+        // a launch or an RCCL call failed half way: nothing of this solve may still be in flight on the exchange
+        // stream when the caller looks at (or destroys) the context; the error message of the failure is kept
+        const std::string why = last_error();
+        (void)hipStreamSynchronize(o.xstream);
+        (void)hipStreamSynchronize(o.compute);
+        last_error() = why;
+    }
+    return rc;
+}
+
+int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
+{
+    if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    SFL_TRY(resolve_schedule(ctx));
+    const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
+    std::vector<std::vector<sfl_plan_step>> progs;
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
+        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse,
+                                          kernel == 2 && in_time_exchanges(ctx) ? 3 : kernel, effective_halo(ctx, fuse),
+                                          ctx->solve_tail));
+        c->last_launches = c->last_exchanges = c->last_chained = 0;
+        c->p_ghost_valid = 0;
+        c->last_fuse = kernel == 1 ? 1 : fuse;
+    }
+    const sfl::SorParams prm = sor_params(dx, omega);
+    if (small_grid(ctx)) {  // one workgroup, p and d in LDS, every iteration in one launch
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(sfl::launch_small_solve(ctx->stream, ctx->p, ctx->div, ctx->dim_x, ctx->gdim_y, iters, prm));
+        ctx->last_launches = 1;
+        ctx->last_fuse = 2 * iters;
+        return SFL_OK;
+    }
+    if (iters == 0) {  // the reference still zero-fills p (poisson.cpp:117-119)
+        for (sfl_context *c : peers) {
+            SFL_TRY(use_device(c));
+            HIP_TRY(sfl::launch_zero_rows(c->stream, c->p, c->geom, c->g0, c->g1));
+        }
+        return SFL_OK;
+    }
+    if (kernel == 2 && ctx->nranks > 1 && ctx->opt_sor_overlap && ctx->transport) {
+        SFL_TRY(run_poisson_overlapped(ctx, peers, progs, prm));
+    } else {
+        for (size_t i = 0; i < progs[0].size(); ++i) {
+            const sfl_plan_step &st0 = progs[0][i];
+            if (st0.kind == SFL_STEP_EXCHANGE) {
+                SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
+            } else if (const int n = chainable_steps(ctx, progs[0], i, false)) {   // same program shape on every peer
+                for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_chain(peers[k], progs[k], i, n, prm));
+                i += n - 1;
+            } else {
+                for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
+            }
+        }
+    }
+    // ghost rows of p the last launch left exact (the plan's tail): what subtract_gradient may read without an exchange
+    int tail = ctx->nranks > 1 ? ctx->solve_tail : 0;
+    for (size_t k = 0; k < peers.size() && tail > 0; ++k) {
+        const sfl_context *c = peers[k];
+        const sfl_plan_step &last = progs[k].back();
+        if (last.kind != SFL_STEP_SOR) tail = 0;
+        if (c->rank > 0) tail = std::min(tail, c->g0 - last.g_begin);
+        if (c->rank < c->nranks - 1) tail = std::min(tail, last.g_end - c->g1);
+    }
+    for (sfl_context *c : peers) c->p_ghost_valid = tail > 0 ? tail : 0;
+    return SFL_OK;
+}
+
+}  // namespace host
+}  // namespace sfl

@@ -423,6 +423,17 @@ struct Lane2 : WaveCommon {
 #ifndef SFL_PROBE_NO_EDGE
 #define SFL_PROBE_NO_EDGE 0  // diagnostic builds only: every tile takes the interior path (wrong results at the walls)
 #endif
+#ifndef SFL_SOR_TRACE
+// The SFL_PROBE_* / SFL_CHAIN_* switches compute WRONG results (or change cache policies the protocol relies on); they exist for
+// tools/sor_clock_probe.hip, which includes this file with SFL_SOR_TRACE defined.  A product library never sees them set:
+// `make EXTRA_FLAGS=-DSFL_PROBE_NO_LOAD=1` stops here.
+#ifdef SFL_PROBE_COOP
+#error "SFL_PROBE_COOP is a timing mock (wrong results): only with SFL_SOR_TRACE (tools/sor_clock_probe.hip)"
+#endif
+static_assert(SFL_PROBE_NO_LDS == 0 && SFL_PROBE_NO_LOAD == 0 && SFL_PROBE_SHIFT == 0 && SFL_PROBE_NO_EDGE == 0 &&
+                  SFL_PROBE_P_LOAD_AUX == 0 && SFL_PROBE_P_STORE_AUX == 0,
+              "SFL_PROBE_* switches give wrong results: diagnostic builds only (define SFL_SOR_TRACE, tools/sor_clock_probe.hip)");
+#endif
 constexpr int min_waves_per_simd(int ns) { return ns == 14 ? 2 : ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }
 
 // One tile: its NS passes over output rows rect.[r0, r1) of strip rect.strip, from p_in (ZERO_IN: from zero) to p_out.
@@ -546,13 +557,16 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
         bool arrived = true;
         while ((int)((unsigned)__hip_atomic_load(hw.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)hw.epoch) < 0) {
             __builtin_amdgcn_s_sleep(20);
-            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)hw.timeout_us) {
                 arrived = false;
                 break;
             }
         }
         if (!arrived && lane == 0) atomicOr(hw.timed_out, 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (hw.system_scope)   // (wave-uniform) rows written by a peer GPU over xGMI
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        else
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 
     // a SENDER tile (kernels.h HaloWait::done): its output rows are part of the next halo message
@@ -606,6 +620,10 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
 #ifndef SFL_CHAIN_SLEEP
 #define SFL_CHAIN_SLEEP 1
 #endif
+#ifndef SFL_SOR_TRACE
+static_assert(SFL_PROBE_CHAIN_NO_DEPS == 0 && SFL_CHAIN_ST == 16 && SFL_CHAIN_LD == 16,
+              "the chained launch's hand-off needs written-through stores, L1-bypassing loads and its waits: diagnostic builds only");
+#endif
 struct ChainLink {
     sor::Tiling t;
     HaloWait hw;
@@ -614,6 +632,7 @@ struct ChainLink {
 };
 struct ChainArgs {
     int n_steps, waves, epoch;
+    int timeout_us;
     int *flags;
     int *timed_out;
     ChainLink link[kMaxChain];
@@ -630,7 +649,7 @@ __device__ __forceinline__ int chain_reach(const Slab &g)
 
 // Wait until every tile of tiling `prev` whose output rows intersect [lo, hi) in strips strip - 1 .. strip + 1 has published
 // `want` (or a later value).  Lane k polls the k-th such tile; one relaxed agent-scope load per lane and turn.
-__device__ __forceinline__ __attribute__((unused)) bool chain_wait(const sor::Tiling &prev, int strip, int lo, int hi, const int *flags, int want, int lane)
+__device__ __forceinline__ __attribute__((unused)) bool chain_wait(const sor::Tiling &prev, int strip, int lo, int hi, const int *flags, int want, int lane, int timeout_us)
 {
     int c0[3], n[3] = {0, 0, 0};
 #pragma unroll
@@ -650,7 +669,7 @@ __device__ __forceinline__ __attribute__((unused)) bool chain_wait(const sor::Ti
             const bool behind = idx >= 0 && (int)((unsigned)__hip_atomic_load(flags + (size_t)idx * SFL_CHAIN_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) < 0;
             if (!__builtin_amdgcn_ballot_w64(behind)) break;
             __builtin_amdgcn_s_sleep(SFL_CHAIN_SLEEP);
-            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)timeout_us) return false;
         }
     }
     return true;
@@ -688,7 +707,7 @@ sor_chain_kernel(float *pa, float *pb, const float *d, Slab g, SorParams prm, Ch
             // the previous superstep's tiles around this one: their output is this tile's input, and this tile's output
             // replaces their input (the two arrays take turns)
             if (s > 0 && !SFL_PROBE_CHAIN_NO_DEPS)
-                late = chain_wait(a.link[s - 1].t, rect.strip, r0 - reach, r1 + reach, a.flags, a.epoch + s, lane) ? 0 : 2;
+                late = chain_wait(a.link[s - 1].t, rect.strip, r0 - reach, r1 + reach, a.flags, a.epoch + s, lane, a.timeout_us) ? 0 : 2;
             // the halo message of the exchange in front of this superstep (see sor_fused_kernel; no acquire: sc1 loads), and
             // the message two supersteps back whose source this tile overwrites (kernels.h ChainStep::guard_flag)
             const bool incoming = hw.flag != nullptr && (r0 - reach < hw.own_lo || r1 + reach > hw.own_hi);
@@ -699,7 +718,7 @@ sor_chain_kernel(float *pa, float *pb, const float *d, Slab g, SorParams prm, Ch
                 const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
                 while ((int)((unsigned)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) < 0) {
                     __builtin_amdgcn_s_sleep(20);
-                    if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
+                    if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)a.timeout_us) {
                         late |= 4;
                         break;
                     }
@@ -811,7 +830,8 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     t1.rotate = t2.rotate = SFL_PRIO_FORCE >= 0 ? SFL_PRIO_FORCE
                                           : tiles <= resident_waves<B, NS, DX1, ZERO_IN>() && 2 * tiles > 5 * device_simds();
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0};
+    HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0};
+    if (hw.timeout_us <= 0) hw.timeout_us = kHaloWaitDefaultTimeoutUs;
     if (senders) {   // the same test as the kernel's, on the same tilings
         int n = 0;
         if (hw.done)
@@ -848,6 +868,7 @@ hipError_t launch_chain_variant(hipStream_t s, float *pa, float *pb, const float
     a.epoch = epoch;
     a.flags = flags;
     a.timed_out = timed_out;
+    a.timeout_us = steps[0].hw.timeout_us > 0 ? steps[0].hw.timeout_us : kHaloWaitDefaultTimeoutUs;
     int most = 0;
     for (int i = 0; i < n_steps; ++i) {
         const ChainStep &st = steps[i];

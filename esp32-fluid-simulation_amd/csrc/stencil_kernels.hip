@@ -515,21 +515,21 @@ hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value)
     return hipGetLastError();
 }
 
-__global__ void wait_count_kernel(const int *count, int target, int *timed_out)
+__global__ void wait_count_kernel(const int *count, int target, int *timed_out, int timeout_us)
 {
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
     while ((int)((unsigned)__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)target) < 0) {
         __builtin_amdgcn_s_sleep(20);
-        if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)kHaloWaitTimeoutUs) {
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > 100ull * (unsigned long long)timeout_us) {
             if (threadIdx.x == 0) atomicOr(timed_out, 8);
             break;
         }
     }
 }
 
-hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out)
+hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out, int timeout_us)
 {
-    wait_count_kernel<<<1, 64, 0, s>>>(count, target, timed_out);
+    wait_count_kernel<<<1, 64, 0, s>>>(count, target, timed_out, timeout_us > 0 ? timeout_us : kHaloWaitDefaultTimeoutUs);
     return hipGetLastError();
 }
 

@@ -128,6 +128,10 @@ class Solver:
         """This rank's program alone, halo messages as self-copies (timing only; sfl_comm_emulate)."""
         capi.check(self._lib.sfl_comm_emulate(self._h))
 
+    def comm_emulate_rccl(self):
+        """This rank's program alone with real RCCL messages to itself as the transport (timing only; sfl_comm_emulate_rccl)."""
+        capi.check(self._lib.sfl_comm_emulate_rccl(self._h))
+
     @staticmethod
     def link_group(solvers):
         """Join slabs living on one device into an in-process group (virtual ranks)."""

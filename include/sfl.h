@@ -76,7 +76,8 @@ extern "C" {
 #define SFL_OPT_SOR_ROWS 3        /* output rows per wave tile of kernel 2 (0 = auto)            */
 #define SFL_OPT_TRANSPORT 4       /* READ ONLY: 0 = none (whole domain / not attached yet),
                                      1 = RCCL (sfl_comm_attach), 2 = in-process (sfl_group_link),
-                                     3 = emulated (sfl_comm_emulate: timing only)                 */
+                                     3 = emulated (sfl_comm_emulate: timing only), 4 = emulated with RCCL
+                                     messages to the rank itself (sfl_comm_emulate_rccl: timing only) */
 #define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto or 2 (the only flavour
                                      left: round 1's packed 4-cell tiles were never faster)        */
 #define SFL_OPT_SOR_HALO 6        /* rows of p a superstep's halo makes valid on a slab (kernel 2): 0 =
@@ -110,14 +111,20 @@ extern "C" {
                                      back by this many microseconds on the exchange stream before its copy
                                      starts -- the latency of a real xGMI send / receive that a self-copy does
                                      not have; 0 (default) .. 10000                                   */
-#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, with SFL_OPT_SOR_OVERLAP: 1 (default) = exchanges IN TIME, counted on the device
+#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, with SFL_OPT_SOR_OVERLAP: -1 (default) = automatic: 1 on virtual ranks and emulated
+                                     ranks, 0 on RCCL ranks whose peers are other processes (a launch that waits inside the
+                                     kernel is only as safe as its peer is punctual; the scheme has not run on more than one
+                                     GPU yet: tools/first_multi_gpu.sh) -- and 0 wherever the context's compute and exchange
+                                     stream were found NOT to run side by side (measured once, at attach / first solve; RCCL
+                                     ranks agree on it collectively).  1 = exchanges IN TIME, counted on the device
                                      (sfl_plan_poisson kernel 3): the halo of a superstep is exchanged after the launch that
                                      produces it; that launch runs the tiles whose rows the message carries at the top priority,
                                      writes through, and counts them; the message leaves on that count while the rest of the
                                      launch is still running; the next launch is queued at once and only its tiles next to a
                                      cut wait, INSIDE the launch, for a count of arrived messages -- no event on the compute
-                                     stream, no launch on the ghost rows, no launch split.  A wait of more than 2 s gives up
-                                     and is reported by sfl_synchronize.
+                                     stream, no launch on the ghost rows, no launch split.  A wait that outlasts
+                                     SFL_OPT_HALO_TIMEOUT_MS gives up; sfl_synchronize reports it, sfl_download and the next
+                                     operator on the context fail instead of handing out / building on an invalid field.
                                      0 = early exchanges behind cross-stream events (round 3): the halo travels one launch
                                      early, its ghost rows are relaxed behind the message, the launch after waits whole   */
 #define SFL_OPT_STEP_SEAMS 14      /* sfl_step_n on a whole-domain context with the tile kernels: 1 (default) = between two steps
@@ -137,6 +144,14 @@ extern "C" {
                                      advection of the rows further than L from both cuts that it had queued BEFORE reading the
                                      previous step's report (they need no halo; the report says whether that held); 0 = the step
                                      advected everything after the report                                            */
+
+#define SFL_OPT_HALO_TIMEOUT_MS 18  /* limit of a wait INSIDE a launch or on the exchange stream (SFL_OPT_SOR_ARRIVAL = 1, chained launches),
+                                     milliseconds: 0 (default) = the transport's own: 2 s where every party is this process
+                                     (virtual ranks, emulated ranks), 300 s on RCCL ranks -- a peer process may simply be late
+                                     (I/O, a garbage collection), and what used to be an event wait must not become an error */
+#define SFL_OPT_EXCHANGE_SCHEDULE 19 /* READ ONLY: how the next solve on this slab will order its halo exchanges: 0 = none to
+                                     order (whole domain, no transport, the baseline kernel), 1 = in line, 2 = one launch early
+                                     behind cross-stream events, 3 = in time, counted on the device                        */
 
 typedef struct sfl_context sfl_context;
 
@@ -296,6 +311,14 @@ SFL_API int sfl_comm_loopback(sfl_context *ctx, int rows);
  * the values next to the cuts are meaningless (never use the results).  SFL_OPT_TRANSPORT reads 3.
  * bench.py --emulate-rank R --of N reports the time of one solve on such a context.                 */
 SFL_API int sfl_comm_emulate(sfl_context *ctx);
+/* The same rank program with RCCL ITSELF as the transport: a one-rank communicator is created for the context and every halo
+ * message becomes a real ncclSend / ncclRecv of this rank to itself, issued through the very code path a rank of a real
+ * communicator takes (one ncclGroup per exchange on the exchange stream, the sender count in front of it and the arrival
+ * count behind it when exchanges are counted on the device); the step's reductions over the ranks run as ncclAllReduce on
+ * that communicator.  What one GPU can show of the multi-GPU path: RCCL's own kernels beside the solve's launches, their
+ * launch latency, their stream semantics.  SFL_OPT_TRANSPORT reads 4; values next to the cuts are meaningless.
+ * bench.py --emulate-rank R --of N --via-rccl.                                                                     */
+SFL_API int sfl_comm_emulate_rccl(sfl_context *ctx);
 /* In-process transport between virtual ranks living on ONE device (bring-up / tests):
  * ctxs[r] must be slab r of nranks == n, all created on the same device.                   */
 SFL_API int sfl_group_link(sfl_context **ctxs, int n);
