@@ -318,27 +318,105 @@ def parse_args(argv=None):
     ap.add_argument("--arrival-in-time", action="store_true",
                     help="SFL_OPT_SOR_ARRIVAL = 1: exchanges in time, counted on the device, also where the library would not "
                          "choose them by itself (RCCL ranks whose peers are other processes)")
-    ap.add_argument("--launch-timeout", type=float, default=3600.0,
-                    help="self-launcher (--gpus N without torchrun): seconds after which the ranks are stopped")
+    ap.add_argument("--launch-timeout", type=float, default=400.0,
+                    help="multi-GPU runs: seconds after which the rank processes of ONE attempt are stopped (the launcher then "
+                         "starts fresh ranks with the next exchange schedule; all attempts together stay under 1500 s)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous plumbing only: the ranks touch no GPU (CPU test)")
     return ap.parse_args(argv)
 
 
 # ---------------------------------------------------------------------------------------------
-# parent: `python bench.py --gpus N` with N > 1 and no launcher around it
+# multi-GPU launch: fresh rank processes per ATTEMPT, a chain of exchange schedules to fall back through
 # ---------------------------------------------------------------------------------------------
-def launch_ranks(args):
-    """Start one child per GPU, relay rank 0's JSON line, SUPERVISE them.  This process never touches a GPU
-    (no HIP call, not even a device count): the children are fresh processes, nothing that has initialised a GPU
-    is ever replaced or forked.  RCCL send / recv has no timeout: a rank that dies after the communicator is up
-    would leave its neighbours waiting for ever, so all children are polled; the first one that fails (or an
-    overall deadline, --launch-timeout seconds) takes the others down with it -- they are this process's own
-    children, addressed by PID -- and the launcher exits non-zero."""
+# The three schedules of a slab solve's halo exchanges give the same bits; the fastest one (exchanges in time, counted on
+# the device) waits for messages INSIDE kernels and has never run on more than one real GPU.  A multi-GPU run therefore tries
+# the schedules in this order, each with FRESH rank processes (a process that touched a GPU is never re-executed; a failed
+# attempt's processes are stopped, by PID), and reports which one produced the line and why the earlier ones did not.
+MODES = [("in-time", ["--arrival-in-time"], "in time, counted on the device"),
+         ("by-event", ["--arrival-by-event"], "one launch early, behind events"),
+         ("in-line", ["--no-overlap"], "in line")]
+TOTAL_BUDGET_S = 1500.0
+
+
+def attempt_plan(args):
+    """The schedules a multi-GPU run goes through; a schedule asked for on the command line is the only one tried."""
+    if args.arrival_in_time:
+        return [MODES[0]]
+    if args.arrival_by_event:
+        return [MODES[1]]
+    if args.no_overlap:
+        return [MODES[2]]
+    return list(MODES)
+
+
+def mode_of(args):
+    return "in-time" if args.arrival_in_time else "by-event" if args.arrival_by_event else "in-line" if args.no_overlap else "library default"
+
+
+class Child:
+    """One rank process of one attempt: stdout kept (the JSON line travels on rank 0's), stderr relayed to ours as it comes,
+    its last non-empty line remembered (the reason, should the rank fail)."""
+
+    def __init__(self, cmd, env, keep_stdout):
+        import threading
+        self.p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if keep_stdout else sys.stderr, stderr=subprocess.PIPE,
+                                  text=True)
+        self.lines, self.last_err = [], ""
+        self._threads = [threading.Thread(target=self._relay, daemon=True)]
+        if keep_stdout:
+            self._threads.append(threading.Thread(target=lambda: self.lines.extend(self.p.stdout), daemon=True))
+        for t in self._threads:
+            t.start()
+
+    def _relay(self):
+        for line in self.p.stderr:
+            sys.stderr.write(line)
+            if line.strip():
+                self.last_err = line.strip()[-300:]
+
+    def poll(self):
+        return self.p.poll()
+
+    def stop(self):
+        if self.p.poll() is None:
+            self.p.terminate()
+            t_kill = time.monotonic() + 5.0
+            while self.p.poll() is None and time.monotonic() < t_kill:
+                time.sleep(0.05)
+            if self.p.poll() is None:
+                self.p.kill()
+        self.p.wait()
+
+    def finish(self):
+        for t in self._threads:
+            t.join(timeout=5.0)
+
+    def json_line(self):
+        out = None
+        for l in self.lines:
+            l = l.rstrip("\n")
+            if l.startswith("{"):
+                out = l
+            elif l:
+                print(l, file=sys.stderr)
+        return out
+
+
+def worker_argv(extra):
+    return [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra)
+
+
+def launch_ranks(args, extra=(), deadline_s=None):
+    """ONE attempt of `python bench.py --gpus N` without a launcher around it: start one child per GPU and SUPERVISE them.
+    This process never touches a GPU (no HIP call, not even a device count): the children are fresh processes, nothing that
+    has initialised a GPU is ever replaced or forked.  RCCL send / recv has no timeout: a rank that dies after the communicator
+    is up would leave its neighbours waiting for ever, so all children are polled; the first one that fails (or the deadline)
+    takes the others down with it -- they are this process's own children, addressed by PID.
+    Returns (status, json line or None, reason or None): status 0 = every rank finished, 124 = deadline."""
     import shutil
     import socket
     import tempfile
-    import threading
     with socket.socket() as s:      # a free port for MASTER_PORT (RCCL's bootstrap picks its own)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -347,63 +425,150 @@ def launch_ranks(args):
     base = dict(os.environ)
     base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                  "LOCAL_WORLD_SIZE": str(n), "SFL_RDZV_KEY": f"{os.getpid()}_{port}", "SFL_RDZV_DIR": private,
+                 "SFL_BENCH_WORKER": "1",
                  "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    procs, lines = [], []
+    cmd = worker_argv(extra)
+    deadline = time.monotonic() + (deadline_s if deadline_s is not None else args.launch_timeout)
+    kids, worst, why = [], 0, None
     try:
         for r in range(n):
-            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-            # rank 0's stdout carries the JSON line; everybody else's goes to our stderr
-            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                          stderr=sys.stderr, text=True if r == 0 else None))
-        reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
-        reader.start()
-        deadline = time.monotonic() + args.launch_timeout
-        worst, failed_at = 0, None
+            kids.append(Child(cmd, dict(base, RANK=str(r), LOCAL_RANK=str(r)), keep_stdout=(r == 0)))
+        failed_at = None
         while True:
-            codes = [p.poll() for p in procs]
-            bad = [c for c in codes if c not in (None, 0)]
+            codes = [k.poll() for k in kids]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad and failed_at is None:
-                worst, failed_at = bad[0], time.monotonic()
+                worst, failed_at = bad[0][1], time.monotonic()
                 print(f"bench.py launcher: a rank exited with status {worst}; stopping the others", file=sys.stderr)
             if all(c is not None for c in codes):
                 break
-            if failed_at is not None and time.monotonic() - failed_at > 2.0 or time.monotonic() > deadline:
+            if (failed_at is not None and time.monotonic() - failed_at > 2.0) or time.monotonic() > deadline:
                 if failed_at is None:
                     worst = 124
-                    print(f"bench.py launcher: no result after {args.launch_timeout:.0f} s; stopping the ranks",
-                          file=sys.stderr)
-                for p in procs:
-                    if p.poll() is None:
-                        p.terminate()
-                t_kill = time.monotonic() + 5.0
-                while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
-                    time.sleep(0.05)
-                for p in procs:
-                    if p.poll() is None:
-                        p.kill()
-                for p in procs:
-                    p.wait()
+                    why = f"no result after {deadline_s if deadline_s is not None else args.launch_timeout:.0f} s"
+                    print(f"bench.py launcher: {why}; stopping the ranks", file=sys.stderr)
+                for k in kids:
+                    k.stop()
                 break
             time.sleep(0.05)
-        reader.join(timeout=5.0)
-        for p in procs:
-            rc = p.returncode
-            worst = rc if (rc not in (0, None) and worst == 0) else worst
+        for k in kids:
+            k.finish()
+        for r, k in enumerate(kids):
+            rc = k.p.returncode
+            if rc not in (0, None) and (worst == 0 or (why is None and worst != 124)):
+                worst = worst or rc
+            if rc not in (0, None) and why is None and rc > 0:
+                why = f"rank {r} exited with status {rc}: {k.last_err or 'no message'}"
+        if worst != 0 and why is None:
+            why = next((f"rank {r} ended with status {k.p.returncode}: {k.last_err or 'no message'}"
+                        for r, k in enumerate(kids) if k.p.returncode not in (0, None)), "a rank failed")
     finally:
+        for k in kids:
+            if k.poll() is None:
+                k.stop()
         shutil.rmtree(private, ignore_errors=True)
-    line = None
-    for l in lines:
-        l = l.rstrip("\n")
-        if l.startswith("{"):
-            line = l
-        elif l:
-            print(l, file=sys.stderr)
-    if line:
-        print(line, flush=True)
-    elif worst == 0:
-        worst = 1
-    return worst
+    line = kids[0].json_line() if kids else None
+    if worst == 0 and not line:
+        worst, why = 1, "rank 0 printed no JSON line"
+    return worst, line, why
+
+
+def annotate(line, mode, failures):
+    """The winning attempt's JSON line with the schedule that produced it and the attempts that did not."""
+    try:
+        d = json.loads(line)
+    except ValueError:
+        return line
+    d["exchange_mode"] = mode
+    d["fallback_from"] = failures
+    return json.dumps(d)
+
+
+def launch_with_fallback(args):
+    """`python bench.py --gpus N`, N > 1, as typed: the schedules of attempt_plan() one after the other until one gives a
+    line, within TOTAL_BUDGET_S; non-zero with every attempt's reason when none does."""
+    t_begin, failures, status = time.monotonic(), [], 1
+    plan = attempt_plan(args)
+    for k, (mode, flags, _) in enumerate(plan):
+        left = TOTAL_BUDGET_S - (time.monotonic() - t_begin)
+        if left < 30.0:
+            failures.append({"mode": mode, "why": "not tried: the total budget of the launcher was spent"})
+            continue
+        extra = list(flags) if len(plan) > 1 else []
+        if mode == "in-time" and not args.halo_timeout_ms and len(plan) > 1:
+            extra += ["--halo-timeout-ms", "20000"]     # a lost message is to end as an error line, not as a stopped process
+        status, line, why = launch_ranks(args, extra, min(args.launch_timeout, left - 10.0))
+        if status == 0 and line:
+            print(annotate(line, mode if len(plan) > 1 else mode_of(args), failures), flush=True)
+            return 0
+        failures.append({"mode": mode, "status": status, "why": why})
+        if k + 1 < len(plan):
+            print(f"bench.py launcher: schedule '{mode}' failed ({why}); starting fresh ranks with '{plan[k + 1][0]}'",
+                  file=sys.stderr)
+    print("bench.py launcher: every exchange schedule failed: " + json.dumps(failures), file=sys.stderr)
+    return status or 1
+
+
+def supervise_rank(args):
+    """Started per rank by `python -m torch.distributed.run ... bench.py --gpus N` (the driver's command line): this process
+    is rank R's SUPERVISOR.  It never touches a GPU; per attempt it starts ONE fresh worker (the same command line + the
+    schedule's flag), and the N supervisors agree -- over the TCP rendezvous, twice a second -- on whether the attempt is
+    still running, has succeeded on every rank, or has failed on any (then every supervisor stops its worker and all go on to
+    the next schedule together).  The launcher around us would end the whole run at the first non-zero exit: supervisors only
+    exit non-zero when every schedule has failed."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"])
+    from importlib import import_module
+    Rendezvous = import_module(PKG + ".rendezvous").Rendezvous
+    base_key = os.environ.get("SFL_RDZV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+    sup = Rendezvous(rank, world, key=base_key + "_sup")
+    t_begin, failures, status = time.monotonic(), [], 1
+    plan = attempt_plan(args)
+    try:
+        for k, (mode, flags, _) in enumerate(plan):
+            left = TOTAL_BUDGET_S - (time.monotonic() - t_begin)
+            go = sup.all_gather(left >= 30.0)[0]          # rank 0's clock decides for everybody
+            if not go:
+                failures.append({"mode": mode, "why": "not tried: the total budget of the launcher was spent"})
+                continue
+            extra = list(flags) if len(plan) > 1 else []
+            if mode == "in-time" and not args.halo_timeout_ms and len(plan) > 1:
+                extra += ["--halo-timeout-ms", "20000"]
+            env = dict(os.environ, SFL_BENCH_WORKER="1", SFL_RDZV_KEY=f"{base_key}_w{k}",
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            kid = Child(worker_argv(extra), env, keep_stdout=(rank == 0))
+            deadline = time.monotonic() + min(args.launch_timeout, left - 10.0)
+            verdict = None
+            while verdict is None:
+                time.sleep(0.25)
+                rc = kid.poll()
+                mine = "running" if rc is None else ("ok" if rc == 0 else f"rank {rank} exited with status {rc}: {kid.last_err or 'no message'}")
+                if rank == 0 and rc is None and time.monotonic() > deadline:
+                    mine = f"no result after {min(args.launch_timeout, left - 10.0):.0f} s"
+                states = sup.all_gather(mine)
+                broken = [st for st in states if st not in ("running", "ok")]
+                if broken:
+                    verdict = broken[0]
+                elif all(st == "ok" for st in states):
+                    verdict = "ok"
+            kid.stop()
+            kid.finish()
+            if verdict == "ok":
+                line = kid.json_line() if rank == 0 else None
+                if rank != 0 or line:
+                    if rank == 0:
+                        print(annotate(line, mode if len(plan) > 1 else mode_of(args), failures), flush=True)
+                    status = 0
+                    sup.barrier()
+                    return 0
+                verdict = "rank 0 printed no JSON line"
+            failures.append({"mode": mode, "why": verdict})
+            if rank == 0 and k + 1 < len(plan):
+                print(f"bench.py: schedule '{mode}' failed ({verdict}); starting fresh ranks with '{plan[k + 1][0]}'", file=sys.stderr)
+        if rank == 0:
+            print("bench.py: every exchange schedule failed: " + json.dumps(failures), file=sys.stderr)
+        return status or 1
+    finally:
+        sup.close()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -429,11 +594,16 @@ def run_rank(args):
             os._exit(7)
         if os.environ.get("SFL_BENCH_TEST_HANG"):                      # launcher test: ranks that never finish
             time.sleep(3600)
+        if mode_of(args) in os.environ.get("SFL_BENCH_TEST_FAIL_MODES", "").split(","):   # launcher test: a schedule that fails
+            print(f"bench.py rank {rank}: schedule '{mode_of(args)}' made to fail by the test", file=sys.stderr)
+            os._exit(9)
+        if mode_of(args) in os.environ.get("SFL_BENCH_TEST_HANG_MODES", "").split(","):   # ... or never finishes
+            time.sleep(3600)
         rdzv.barrier()
         top = rdzv.max([float(rank), 1.0])
         ranks = rdzv.all_gather({"rank": rank, "token": token.hex()})
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank": top[0],
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank": top[0], "mode": mode_of(args),
                               "tokens_agree": len({r["token"] for r in ranks}) == 1,
                               "ranks": [r["rank"] for r in ranks]}), flush=True)
         rdzv.barrier()
@@ -842,10 +1012,12 @@ def run_rank(args):
 
 def main():
     args = parse_args()
-    in_launcher = int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if args.gpus > 1 and not in_launcher:
-        sys.exit(launch_ranks(args))
-    sys.exit(run_rank(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("SFL_BENCH_WORKER") or (args.gpus <= 1 and world <= 1):
+        sys.exit(run_rank(args))            # one rank: a worker of one of the launchers below, or the one-GPU run itself
+    if world > 1:
+        sys.exit(supervise_rank(args))      # started per rank by torch.distributed.run: supervise one worker per attempt
+    sys.exit(launch_with_fallback(args))    # `python bench.py --gpus N` as typed: start and supervise N workers per attempt
 
 
 if __name__ == "__main__":

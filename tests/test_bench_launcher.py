@@ -61,7 +61,8 @@ def test_bench_self_launch_as_typed():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode == 0, r.stderr
     out = _json_line(r.stdout)
-    assert out == {"dry_run": True, "n_gpus": 3, "max_rank": 2.0, "tokens_agree": True, "ranks": [0, 1, 2]}
+    assert out == {"dry_run": True, "n_gpus": 3, "max_rank": 2.0, "mode": "in-time", "tokens_agree": True, "ranks": [0, 1, 2],
+                   "exchange_mode": "in-time", "fallback_from": []}
 
 
 def test_bench_under_torch_distributed_run():
@@ -113,3 +114,90 @@ def test_self_launcher_deadline():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "3"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+
+
+# ---- round 5: a chain of exchange schedules, fresh rank processes per attempt ------------------------
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SFL_BENCH_WORKER")}
+    env.update(extra)
+    return env
+
+
+def test_one_gpu_line_has_no_launcher_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=_clean_env())
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert "exchange_mode" not in out and "fallback_from" not in out and out["mode"] == "library default"
+
+
+def test_self_launcher_falls_back_to_the_next_schedule():
+    """The default schedule (exchanges in time) fails on a rank: fresh ranks are started with early exchanges behind events,
+    the line says which schedule produced it and why the first did not."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True,
+                       text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "by-event" and out["mode"] == "by-event" and out["n_gpus"] == 3
+    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
+    assert "made to fail by the test" in out["fallback_from"][0]["why"]
+
+
+def test_self_launcher_falls_back_past_a_schedule_that_hangs():
+    """... or never finishes: the per-attempt deadline stops its ranks, the next schedule gets fresh ones."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "4"],
+                       capture_output=True, text=True, timeout=300,
+                       env=_clean_env(SFL_BENCH_TEST_HANG_MODES="in-time", SFL_BENCH_TEST_FAIL_MODES="by-event"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "in-line"
+    assert [f["mode"] for f in out["fallback_from"]] == ["in-time", "by-event"]
+    assert "no result after 4 s" in out["fallback_from"][0]["why"] and out["fallback_from"][0]["status"] == 124
+
+
+def test_self_launcher_reports_every_schedules_reason_when_all_fail():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event,in-line"))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    tail = [l for l in r.stderr.splitlines() if "every exchange schedule failed" in l]
+    assert len(tail) == 1
+    reasons = json.loads(tail[0].split("failed: ", 1)[1])
+    assert [f["mode"] for f in reasons] == ["in-time", "by-event", "in-line"]
+    assert all("made to fail by the test" in f["why"] for f in reasons)
+
+
+def test_a_schedule_asked_for_is_the_only_one_tried():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--arrival-by-event"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="by-event"))
+    assert r.returncode != 0 and "starting fresh ranks" not in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-overlap"],
+                       capture_output=True, text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event"))
+    assert r.returncode == 0 and _json_line(r.stdout)["exchange_mode"] == "in-line"
+
+
+@pytest.mark.parametrize("broken", ["fail", "hang"])
+def test_fallback_under_torch_distributed_run(broken):
+    """The driver's command line: torch.distributed.run starts one bench.py per rank; each is its rank's supervisor, starts a
+    fresh worker per attempt, and the supervisors agree on failing over to the next schedule together -- none of them exits
+    non-zero in between (the elastic agent would end the run)."""
+    env = _clean_env(**({"SFL_BENCH_TEST_FAIL_MODES": "in-time"} if broken == "fail" else {"SFL_BENCH_TEST_HANG_MODES": "in-time"}))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641" if broken == "fail" else "29643",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "5"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["exchange_mode"] == "by-event" and out["tokens_agree"]
+    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
+    assert ("made to fail by the test" if broken == "fail" else "no result after 5 s") in out["fallback_from"][0]["why"]
+
+
+def test_all_schedules_failing_under_torch_distributed_run():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29645",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event,in-line"))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "every exchange schedule failed" in r.stderr
