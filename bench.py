@@ -622,14 +622,8 @@ def run_rank(args):
             sys.exit("--emulate-rank runs on ONE GPU")
         s = sfl.Solver(size, dim_y, device=local_rank, rank=args.emulate_rank, nranks=args.of)
         if args.via_rccl:
-            sys.stdout.flush()          # (RCCL's banner goes to stdout: keep it off the JSON line)
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+            with sfl.stdout_to_stderr():   # (RCCL's banner goes to stdout: keep it off the JSON line)
                 s.comm_emulate_rccl()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
         else:
             s.comm_emulate()
         if args.wire_us:
@@ -658,14 +652,8 @@ def run_rank(args):
         uid = rdzv.broadcast_bytes(sfl.comm_unique_id() if rank == 0 else None)
         # RCCL prints a version banner on stdout while the communicator comes up; keep stdout
         # clean for the ONE JSON line by pointing fd 1 at stderr for the duration of the call
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with sfl.stdout_to_stderr():
             s.comm_attach(uid)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
 
     # synthetic inputs, resident in HBM before anything is timed
     s.upload(capi.FIELD_VELOCITY, synthetic_velocity(size, s.row_begin, s.row_end))
@@ -717,6 +705,7 @@ def run_rank(args):
     elapsed, ev_ms = timed_region()
     info = s.last_solve_info()
     schedule = s.get_option(capi.OPT_EXCHANGE_SCHEDULE)
+    exchange_us = s.get_option(capi.OPT_MEASURED_WIRE_US)    # -1: nothing to measure (one GPU)
     try:
         info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
     except sfl.SflError:                                        # (an older library under tools/with_lib.py)
@@ -877,6 +866,7 @@ def run_rank(args):
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
             "emulated_wire_us": args.wire_us, "transport": "rccl-to-self" if args.via_rccl else "copy-kernel",
             "exchange_schedule": SCHEDULES.get(schedule, schedule),
+            "halo_rows_per_superstep": info["halo"], "measured_exchange_latency_us": exchange_us,
             "sim_step_us": (1e6 / sim_sps) if sim_sps else None, **({"sim_steps_note": sim_note} if sim_note else {}),
             "note": "one rank's program alone on one GPU, halo messages as self-copies of the same size on the "
                     "exchange stream (sfl_comm_emulate); values next to the cuts are meaningless",
@@ -961,6 +951,7 @@ def run_rank(args):
                        "supersteps_in_chained_launches": info["chained"],
                        "halo_exchanges_per_solve": info["exchanges"],
                        "exchange_schedule": SCHEDULES.get(schedule, schedule),
+                       "halo_rows_per_superstep": info["halo"], "measured_exchange_latency_us": exchange_us,
                        "half_sweeps_fused_per_launch": info["fuse"]},
             "parity": parity,
             **({"sim_step_parity": step_parity} if step_parity is not None else {}),

@@ -15,8 +15,8 @@ call that needs the library fails loudly if it is missing -- there is no CPU fal
 from . import _capi as capi
 from ._capi import LIB_PATH, SflError, build_library
 from .solver import (HostPath, Solver, comm_unique_id, device_count, device_info, plan_poisson,
-                     slab_rows, sor_pass_plan)
+                     slab_rows, sor_pass_plan, stdout_to_stderr)
 
 __all__ = ["capi", "LIB_PATH", "SflError", "build_library", "HostPath", "Solver",
            "comm_unique_id", "device_count", "device_info", "plan_poisson", "slab_rows",
-           "sor_pass_plan"]
+           "sor_pass_plan", "stdout_to_stderr"]

@@ -26,6 +26,8 @@ OPT_LAST_CHAINED = 16
 OPT_LAST_EARLY_ROWS = 17
 OPT_HALO_TIMEOUT_MS = 18
 OPT_EXCHANGE_SCHEDULE = 19
+OPT_MEASURED_WIRE_US = 20
+OPT_LAST_HALO = 21
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128

@@ -366,8 +366,8 @@ static int set_option_one(sfl_context *c, int option, int value)
             c->opt_sor_fuse = value;
             return SFL_OK;
         case SFL_OPT_ADVECT_HALO:
-            if (value < 0 || value > kGhostRows)
-                return fail(SFL_ERR_INVALID, "advect halo must be 0 (auto) or 1..%d rows", kGhostRows);
+            if (value < 0 || value > kAdvectGhostRows)
+                return fail(SFL_ERR_INVALID, "advect halo must be 0 (auto) or 1..%d rows", kAdvectGhostRows);
             c->opt_advect_halo = value;
             return SFL_OK;
         case SFL_OPT_SOR_ROWS:
@@ -379,11 +379,14 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_LAST_CHAINED:
         case SFL_OPT_LAST_EARLY_ROWS:
         case SFL_OPT_EXCHANGE_SCHEDULE:
+        case SFL_OPT_MEASURED_WIRE_US:
+        case SFL_OPT_LAST_HALO:
             return fail(SFL_ERR_INVALID, "this option is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
         case SFL_OPT_SOR_OVERLAP:
+            if (c->opt_sor_overlap != (value ? 1 : 0)) c->exchange_latency_us = -1;
             c->opt_sor_overlap = value ? 1 : 0;
             return SFL_OK;
         case SFL_OPT_FUSE_DIVERGENCE:
@@ -399,8 +402,10 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_EMULATE_WIRE_US:
             if (value < 0 || value > 10000) return fail(SFL_ERR_INVALID, "emulated wire delay must be 0..10000 us");
             c->opt_emulate_wire_us = value;
+            c->exchange_latency_us = -1;   // what an exchange costs is measured again before the next solve
             return SFL_OK;
         case SFL_OPT_SOR_ARRIVAL:
+            if (c->opt_sor_arrival != (value < 0 ? -1 : (value ? 1 : 0))) c->exchange_latency_us = -1;   // (measured with the other protocol)
             c->opt_sor_arrival = value < 0 ? -1 : (value ? 1 : 0);
             return SFL_OK;
         case SFL_OPT_HALO_TIMEOUT_MS:
@@ -454,6 +459,11 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;
         case SFL_OPT_TRANSPORT: *value = c->transport ? c->transport->kind() : 0; return SFL_OK;
         case SFL_OPT_HALO_TIMEOUT_MS: *value = c->opt_halo_timeout_ms; return SFL_OK;
+        case SFL_OPT_LAST_HALO: *value = c->last_halo; return SFL_OK;
+        case SFL_OPT_MEASURED_WIRE_US:
+            if (c->transport && c->nranks > 1 && c->exchange_latency_us < 0) SFL_TRY(measure_exchange(c));
+            *value = c->exchange_latency_us;
+            return SFL_OK;
         case SFL_OPT_EXCHANGE_SCHEDULE: {   // what the next solve will do: needs the streams' verdict (transport.cpp)
             if (!c->transport || c->nranks < 2 || c->opt_sor_kernel == 1) { *value = 0; return SFL_OK; }
             bool side_by_side = false;

@@ -57,7 +57,9 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 namespace sfl {
 namespace host {
 
-constexpr int kGhostRows = 64;  // ghost rows allocated per side on a slab (nranks > 1)
+constexpr int kGhostRows = 160;      // ghost rows allocated per side on a slab (nranks > 1): the deepest halo a solve's superstep may use
+constexpr int kAdvectGhostRows = 64;  // ... of which an advection's halo may use this many (beyond: the field is gathered)
+constexpr int kLegacySorHalo = 64;    // the solve's halo before it was chosen from the measured exchange (still its starting point)
 constexpr size_t kAlternateSweepCells = 48u << 20;  // local cells from which successive SOR launches alternate direction
 // Reach words of a slab (device ints, atomicMax'ed by backtrace_reach_kernel; zero them first):
 //   [0] / [1]  rows the back-traces of the OWNED rows need below / above the slab;  [2] a back-trace left a guessed halo;
@@ -71,6 +73,36 @@ constexpr int kReportWords = kReachWords + 1;
 
 class Transport;
 class Group;
+
+// The automatic halo depth of a slab's solves is DECIDED BY TIMING REAL SOLVES (sor_executor.cpp choose_halo): a model with the
+// measured exchange as its input names up to three candidate depths, each of the first solves of a kind -- same iteration
+// count, fuse depth, tail and schedule -- runs on one of them between two events (every depth gives the same bits), and the
+// fastest is kept for that kind from then on.
+struct HaloTuner {
+    struct Kind {
+        int iters, fuse, tail, in_time;
+        bool operator==(const Kind &o) const { return iters == o.iters && fuse == o.fuse && tail == o.tail && in_time == o.in_time; }
+    };
+    struct Decided {
+        Kind kind;
+        int halo;
+    };
+    static constexpr int kCandidates = 3, kSolvesEach = 3;   // (the first solve on a depth is not timed: new tilings, cold caches)
+    std::vector<Decided> decided;
+    bool active = false;
+    Kind kind{};
+    int cand[kCandidates] = {0, 0, 0}, ncand = 0;
+    int solve_no = 0, pending = -1;      // exploratory solves issued so far; candidate of the solve between the two events
+    bool pending_timed = false;
+    float total_ms[kCandidates] = {0, 0, 0};
+    int timed[kCandidates] = {0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~HaloTuner()
+    {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
 
 }  // namespace host
 }  // namespace sfl
@@ -181,6 +213,12 @@ struct sfl_context {
     std::shared_ptr<sfl::host::Transport> keepalive;   // a dissolved group's streams, while this context still runs on them
     bool options_dirty = false;         // an option changed since the ranks last compared their option blocks
     int streams_concurrent = -1;        // compute and exchange stream were seen to run side by side: 1, seen not to: 0, untested: -1
+    // One halo exchange of this slab's transport, measured at attach / before the first solve (transport.cpp
+    // measure_exchange): microseconds of a message of ~0 rows (latency: launch, protocol, wire) and nanoseconds per further
+    // row of p (bandwidth).  Maximum over the ranks: every rank derives the same halo depth from it.  -1: not measured.
+    int exchange_latency_us = -1, exchange_ns_per_row = 0;
+    int last_halo = 0;                  // halo depth of the last solve's plan (SFL_OPT_LAST_HALO)
+    sfl::host::HaloTuner halo_tuner;    // (a linked group keeps its own: Group::halo_tuner)
 
     int last_launches = 0, last_exchanges = 0, last_fuse = 0, last_chained = 0;
     int solve_tail = 0;   // ghost rows of p the next solve must leave exact (slab_step_auto: 1, for subtract_gradient)
@@ -225,6 +263,10 @@ SorParams sor_params(float dx, float omega);
 bool small_grid(const sfl_context *c);
 // halo timeout of the waits inside this context's launches, microseconds (kernels.h HaloWait::timeout_us)
 int halo_timeout_us(const sfl_context *c);
+// will the next solve count its halo exchanges on the device (SFL_OPT_SOR_ARRIVAL resolved; the streams' verdict is in)?
+bool in_time_exchanges(const sfl_context *c);
+// halo depth of a solve's supersteps: the option, or chosen from the measured exchange (sor_executor.cpp)
+int effective_halo(const sfl_context *c, int fuse, int iters, bool in_time);
 
 // ---- operators.cpp ----
 struct AdvectPlan {

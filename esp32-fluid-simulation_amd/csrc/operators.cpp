@@ -73,7 +73,7 @@ static int plan_advect(sfl_context *ctx, const std::vector<sfl_context *> &peers
     int reach = 0;
     SFL_TRY(measure_reach(ctx, peers, dt, &reach));
     plan->flag = false;
-    if (reach <= kGhostRows && reach <= min_owned_rows(ctx))
+    if (reach <= kAdvectGhostRows && reach <= min_owned_rows(ctx))
         plan->halo = reach;
     else
         plan->gather = true;

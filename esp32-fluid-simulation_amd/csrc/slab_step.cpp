@@ -134,7 +134,7 @@ int settle_color(sfl_context *ctx, bool collective)
     // the guess was short: back to the colour the step started with, advect again with what is now known
     AdvectPlan plan;
     plan.flag = false;
-    if (reach <= kGhostRows && reach <= min_owned_rows(ctx))
+    if (reach <= kAdvectGhostRows && reach <= min_owned_rows(ctx))
         plan.halo = reach;
     else
         plan.gather = true;
@@ -160,7 +160,7 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
         SFL_TRY(ensure_field(c, SFL_FIELD_VELOCITY));
         SFL_TRY(ensure(c, c->vel_tmp, 8, false));
     }
-    const int limit = std::min(kGhostRows, min_owned_rows(ctx));
+    const int limit = std::min(kAdvectGhostRows, min_owned_rows(ctx));
     const bool known = ctx->known_reach >= 0 && ctx->known_epoch == ctx->vel_epoch && ctx->known_dt == dt;
     int reach_v = 0, reach_v_ext = 0;  // halo for the owned rows' back-traces / for those of own +- 1 rows
     if (known) {
@@ -255,7 +255,7 @@ static int slab_step_auto(sfl_context *ctx, float dt, float dx, int iters, float
 static int advect_interior_early(sfl_context *ctx, float dt)
 {
     std::vector<sfl_context *> peers = peers_of(ctx);
-    const int limit = std::min(kGhostRows, min_owned_rows(ctx));
+    const int limit = std::min(kAdvectGhostRows, min_owned_rows(ctx));
     for (sfl_context *c : peers)
         if (!c->vel || !c->vel_tmp || c->g1 - c->g0 < 2 * limit + 64) return SFL_OK;   // (nothing worth it, or not set up yet)
     SFL_TRY(use_device(ctx));

@@ -54,14 +54,167 @@ bool small_grid(const sfl_context *c)
 }
 
 
-int effective_halo(const sfl_context *c, int fuse)
+// What a solve of `iters` iterations costs a middle rank (a cut on both sides) of the thinnest slab with halo depth
+// `halo`, in microseconds, by a model with ONE measured input -- the exchange (sfl_context::exchange_latency_us /
+// exchange_ns_per_row, transport.cpp measure_exchange) -- and two constants of this kernel on this chip:
+//   launch        3.5 us of dispatch, ramp-up and drain + 0.2 ps per cell and colour pass over the rows it streams: the
+//                 owned rows plus, on each side, the ghost rows it still has to keep exact and its own warm-up
+//                 (profiles/r04_thin_share_lower_bound.txt: 23.4 us per launch of 8192 x (1024 + 2 x 43) cells at 10 passes;
+//                 profiles/r04_default_fuse16_summary.txt: 176 us per launch of 8192^2 at 16 passes);
+//   exchange      what a message costs the critical path: its measured latency (cross-stream hand-over included) + its rows
+//                 at the measured rate, all of it exposed when the launches are short (profiles/r04_wire_delay_curve.txt:
+//                 0.95 D per exchange at 23 us launches), 0.6 of it when a launch lasts more than twice the message
+//                 (0.62 D at 108 us launches).
+// Only differences between depths matter: a deeper halo trades exchanges for redundantly relaxed ghost rows.
+static double modelled_solve_us(const sfl_context *c, int iters, int fuse, int halo, bool in_time)
 {
-    // auto: 64 rows on slabs of >= 1024 rows (2-3 exchanges per 80-iteration solve, ~5 % extra
-    // rows recomputed), 32 on thinner ones
-    int h = c->opt_sor_halo ? c->opt_sor_halo : (min_owned_rows(c) >= 1024 ? 64 : 32);
-    if (h > min_owned_rows(c)) h = min_owned_rows(c);  // a neighbour can only send rows it owns
+    const int rows = min_owned_rows(c), nranks = c->nranks, mid = nranks > 2 ? 1 : 0;
+    const std::vector<sfl_plan_step> prog = sfl::plan_poisson(c->gdim_y, nranks, mid, iters, fuse, in_time ? 3 : 2, halo, c->solve_tail);
+    int b = 0, e = 0;
+    sfl::slab_rows(c->gdim_y, nranks, mid, &b, &e);
+    const double lat = c->exchange_latency_us, per_row = c->exchange_ns_per_row * 1e-3 * (c->dim_x / 8192.0);
+    double us = 0.0, launch_us = 0.0;
+    int launches = 0;
+    for (const sfl_plan_step &st : prog)
+        if (st.kind == SFL_STEP_SOR) {
+            const double t = 3.5 + (double)(st.g_end - st.g_begin + 2 * st.nsweeps) * c->dim_x * st.nsweeps * 0.2e-6;
+            us += t;
+            launch_us += t;
+            ++launches;
+        }
+    const double per_launch = launches ? launch_us / launches : 0.0;
+    for (const sfl_plan_step &st : prog)
+        if (st.kind == SFL_STEP_EXCHANGE) {
+            const double msg = lat + st.rows * per_row;   // (measured on p: 4-byte rows; the right-hand side's are the same size)
+            us += (per_launch > 2.0 * msg ? 0.6 : 1.0) * msg;
+        }
+    (void)rows;
+    return us;
+}
+
+// Halo depth of a solve's supersteps.  An explicit SFL_OPT_SOR_HALO is taken as given.  Automatic: the depth round 2 - 4 settled
+// on with self-copies as the transport (64 rows on slabs of >= 1024 rows: 2 - 3 exchanges per 80-iteration solve, ~5 % extra
+// rows recomputed; 32 on thinner ones) -- unless the exchange has been measured and the model above predicts at least 3 % for
+// another depth: with RCCL's own kernels as the transport an exchange costs 25 - 30 us more than a copy
+// (profiles/r05_emulate_rccl.txt), and a real wire adds to that; 8192^2 on 8 GPUs then does better with ONE p exchange per
+// solve (80 rows) or none (160) than with two.  Every rank of a group sees the same measurement (its maximum over the ranks)
+// and the same thinnest slab, so all ranks resolve the same depth.
+static int clamp_halo(const sfl_context *c, int fuse, int h)
+{
+    const int thinnest = min_owned_rows(c);
+    if (h > thinnest) h = thinnest;  // a neighbour can only send rows it owns
     if (h > kGhostRows) h = kGhostRows;
     return h < fuse ? fuse : h;
+}
+
+static int legacy_halo(const sfl_context *c, int fuse) { return clamp_halo(c, fuse, min_owned_rows(c) >= 1024 ? kLegacySorHalo : 32); }
+
+// the depth the model likes best (the legacy depth when nothing has been measured)
+static int modelled_best_halo(const sfl_context *c, int fuse, int iters, bool in_time)
+{
+    const int legacy = legacy_halo(c, fuse);
+    if (c->exchange_latency_us < 0 || iters < 1 || c->nranks < 2) return legacy;
+    int best = legacy;
+    double best_us = modelled_solve_us(c, iters, fuse, legacy, in_time);
+    for (int h : {32, 48, 64, 80, 96, 112, 128, 144, 160}) {
+        if (clamp_halo(c, fuse, h) != h || h == legacy) continue;   // (depths the slab cannot carry)
+        const double us = modelled_solve_us(c, iters, fuse, h, in_time);
+        if (us < best_us) {
+            best_us = us;
+            best = h;
+        }
+    }
+    return best;
+}
+
+// What effective_halo answers WITHOUT side effects: the option, a depth already decided for this kind of solve, else the
+// legacy depth (plans queried from outside, the model's own plans).
+int effective_halo(const sfl_context *c, int fuse, int iters, bool in_time)
+{
+    if (c->opt_sor_halo) return clamp_halo(c, fuse, c->opt_sor_halo);
+    const HaloTuner &t = c->group ? c->group->halo_tuner : c->halo_tuner;
+    const HaloTuner::Kind kind{iters, fuse, c->solve_tail, in_time ? 1 : 0};
+    for (const HaloTuner::Decided &d : t.decided)
+        if (d.kind == kind) return d.halo;
+    return legacy_halo(c, fuse);
+}
+
+// Halo depth of THIS solve (see HaloTuner).  Candidates: the legacy depth, the model's favourite, the deepest the slab can
+// carry.  Until the kind is decided, solve after solve runs on the candidates in turn between two events on the compute
+// stream; the elapsed time of a solve is read when the next one is issued (a host wait for a solve that was queued a whole
+// call ago: only during these first 9 solves of a kind).  RCCL ranks decide on the maximum over the ranks -- a collective at
+// the tenth solve, which every rank reaches in step (the ranks of a communicator issue the same calls).  An explicit
+// SFL_OPT_SOR_HALO switches all of this off.
+static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool *timed_solve)
+{
+    *timed_solve = false;
+    HaloTuner &t = ctx->group ? ctx->group->halo_tuner : ctx->halo_tuner;
+    if (ctx->opt_sor_halo || !ctx->transport || ctx->nranks < 2 || iters < 1 || ctx->exchange_latency_us < 0) {
+        t.active = false;
+        t.pending = -1;
+        return effective_halo(ctx, fuse, iters, in_time);
+    }
+    const HaloTuner::Kind kind{iters, fuse, ctx->solve_tail, in_time ? 1 : 0};
+    for (const HaloTuner::Decided &d : t.decided)
+        if (d.kind == kind) {
+            t.pending = -1;
+            return d.halo;
+        }
+    if (!t.active || !(t.kind == kind)) {   // a new kind of solve: name the candidates
+        t.active = true;
+        t.kind = kind;
+        t.ncand = 0;
+        for (int h : {legacy_halo(ctx, fuse), modelled_best_halo(ctx, fuse, iters, in_time), clamp_halo(ctx, fuse, kGhostRows)}) {
+            bool seen = false;
+            for (int k = 0; k < t.ncand; ++k) seen = seen || t.cand[k] == h;
+            if (!seen) t.cand[t.ncand++] = h;
+        }
+        t.solve_no = 0;
+        t.pending = -1;
+        for (int k = 0; k < HaloTuner::kCandidates; ++k) {
+            t.total_ms[k] = 0.0f;
+            t.timed[k] = 0;
+        }
+    }
+    if (t.pending >= 0) {   // the previous exploratory solve: how long did it take?
+        float ms = 0.0f;
+        if (hipEventSynchronize(t.ev1) == hipSuccess && hipEventElapsedTime(&ms, t.ev0, t.ev1) == hipSuccess && t.pending_timed &&
+            ms > 0.0f && ms < 1e5f) {   // (a solve that failed half way left its events in no usable order)
+            t.total_ms[t.pending] += ms;
+            ++t.timed[t.pending];
+        }
+        t.pending = -1;
+    }
+    if (t.ncand > 1 && t.solve_no < t.ncand * HaloTuner::kSolvesEach) {
+        const int k = t.solve_no / HaloTuner::kSolvesEach;
+        t.pending = k;
+        t.pending_timed = t.solve_no % HaloTuner::kSolvesEach != 0;
+        ++t.solve_no;
+        *timed_solve = true;
+        return t.cand[k];
+    }
+    // decide: microseconds per solve of each candidate, the maximum over the ranks where they are separate processes
+    int us[HaloTuner::kCandidates] = {0, 0, 0};
+    for (int k = 0; k < t.ncand; ++k) us[k] = t.timed[k] ? (int)(t.total_ms[k] * 1e3f / t.timed[k] + 0.5f) : (k == 0 ? 0 : 1 << 30);
+    if (t.ncand > 1 && reduces_on_device(ctx)) {
+        int *dev = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&dev), sizeof us) == hipSuccess) {
+            Overlap o;
+            const bool ok = hipMemcpy(dev, us, sizeof us, hipMemcpyHostToDevice) == hipSuccess && overlap_of(ctx, &o) == SFL_OK &&
+                            ctx->transport->allreduce_max(ctx, dev, HaloTuner::kCandidates, o.xstream) == SFL_OK &&
+                            hipStreamSynchronize(o.xstream) == hipSuccess &&
+                            hipMemcpy(us, dev, sizeof us, hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(dev);
+            if (!ok)
+                for (int k = 1; k < t.ncand; ++k) us[k] = 1 << 30;   // (then the legacy depth, on every rank that got this far)
+        }
+    }
+    int best = 0;
+    for (int k = 1; k < t.ncand; ++k)
+        if (us[k] < us[best] && us[k] * 100 < us[0] * 99) best = k;   // (another depth has to beat the legacy one by 1 %)
+    t.decided.push_back(HaloTuner::Decided{kind, t.cand[best]});
+    t.active = false;
+    return t.cand[best];
 }
 
 // Exchanges IN TIME with everything counted on the device (run_poisson_in_time; SFL_OPT_SOR_ARRIVAL) instead of early exchanges
@@ -82,7 +235,13 @@ int resolve_schedule(sfl_context *ctx)
 {
     if (!ctx->transport || ctx->nranks < 2) return SFL_OK;
     bool yes = false;
-    return streams_run_concurrently(ctx, &yes);
+    SFL_TRY(streams_run_concurrently(ctx, &yes));
+    // what an exchange costs (the automatic halo depth is chosen from it): RCCL ranks measured it, collectively, at
+    // attach; ranks that share this host thread do it here, once, when no halo depth was asked for; and everybody again
+    // after an option changed the protocol it was measured with
+    if (ctx->exchange_latency_us < 0 && ctx->opt_sor_halo == 0 && ctx->opt_sor_kernel != 1)
+        SFL_TRY(measure_exchange(ctx));   // (RCCL ranks get here together: each of them changed the option that invalidated it)
+    return SFL_OK;
 }
 
 int halo_timeout_us(const sfl_context *c)
@@ -487,13 +646,23 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
     std::vector<sfl_context *> peers = peers_of(ctx);
     SFL_TRY(resolve_schedule(ctx));
     const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
+    const bool in_time = in_time_exchanges(ctx);
+    bool timed_solve = false;
+    const int halo = kernel == 2 && !small_grid(ctx) ? choose_halo(ctx, fuse, iters, in_time, &timed_solve) : effective_halo(ctx, fuse, iters, in_time);
+    HaloTuner &tuner = ctx->group ? ctx->group->halo_tuner : ctx->halo_tuner;
+    if (timed_solve) {
+        SFL_TRY(use_device(ctx));
+        if (!tuner.ev0) HIP_TRY(hipEventCreate(&tuner.ev0));
+        if (!tuner.ev1) HIP_TRY(hipEventCreate(&tuner.ev1));
+        HIP_TRY(hipEventRecord(tuner.ev0, ctx->stream));
+    }
     std::vector<std::vector<sfl_plan_step>> progs;
     for (sfl_context *c : peers) {
         SFL_TRY(ensure_field(c, SFL_FIELD_DIVERGENCE));
         SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
-        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse,
-                                          kernel == 2 && in_time_exchanges(ctx) ? 3 : kernel, effective_halo(ctx, fuse),
+        progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel == 2 && in_time ? 3 : kernel, halo,
                                           ctx->solve_tail));
+        c->last_halo = kernel == 2 && c->nranks > 1 ? halo : 0;
         c->last_launches = c->last_exchanges = c->last_chained = 0;
         c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
@@ -538,6 +707,10 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         if (c->rank < c->nranks - 1) tail = std::min(tail, last.g_end - c->g1);
     }
     for (sfl_context *c : peers) c->p_ghost_valid = tail > 0 ? tail : 0;
+    if (timed_solve) {
+        SFL_TRY(use_device(ctx));
+        HIP_TRY(hipEventRecord(tuner.ev1, ctx->stream));
+    }
     return SFL_OK;
 }
 

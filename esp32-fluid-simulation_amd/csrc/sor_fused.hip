@@ -517,17 +517,21 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // (each with a private L2); give every XCD a CONTIGUOUS range of tiles instead, so that
     // horizontally / vertically adjacent tiles -- which re-read each other's halo columns and
     // rows -- hit in the same L2.  Speed only: any placement computes the same result.
+    // The blocks that hold tiles which wait for a halo message inside the launch keep the dispatcher's own rotation over the
+    // XCDs and come LAST (sor::tile_of_position has the reason); the contiguous ranges are dealt over the blocks in front.
     const int nblocks = gridDim.x;
     int block = blockIdx.x;
-    {
-        const int per = nblocks >> 3, rem = nblocks & 7;
+    const int free_blocks = t2.n_tiles ? nblocks : (sor::free_tiles(t1) / kWavesPerBlock);
+    if (block < free_blocks) {
+        const int per = free_blocks >> 3, rem = free_blocks & 7;
         const int xcd = block & 7, idx = block >> 3;
-        block = xcd * per + min(xcd, rem) + idx;  // bijective for every nblocks
+        block = xcd * per + min(xcd, rem) + idx;  // bijective on [0, free_blocks) for every count
     }
     // a launch covers up to two row ranges (the two cut-adjacent bands of a slab in one launch):
     // the tiles of the second tiling follow those of the first
     int tile = block * kWavesPerBlock + wave;
     if (tile >= t1.n_tiles + t2.n_tiles) return;
+    if (tile < t1.n_tiles) tile = sor::tile_of_position(t1, tile);
 #ifdef SFL_SOR_TRACE
     WaveTrace trace;
     trace.begin();
@@ -832,6 +836,25 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0};
     if (hw.timeout_us <= 0) hw.timeout_us = kHaloWaitDefaultTimeoutUs;
+    if (hw.flag != nullptr && t2.n_tiles == 0) {
+        // the tiles that will wait inside the launch go last (sor::tile_of_position): the same test as the kernel's, on the
+        // chunks of an inner strip and of a boundary strip (chunks are numbered bottom-up: the free ones are one range)
+        const int line_rows = (g.dim_x & 63) ? 1 + 63 / g.dim_x : 0;
+        const int reach = NS + sor::ring_rows(NS) + line_rows;
+        auto free_range = [&](int strip, int n_chunks, int *c0, int *c1) {
+            *c0 = *c1 = 0;
+            bool any = false;
+            for (int c = 0; c < n_chunks; ++c) {
+                const sor::TileRect r = sor::tile_rect(t1, sor::tile_index(t1, strip, c));
+                if (r.r0 - reach < hw.own_lo || r.r1 + reach > hw.own_hi) continue;
+                if (!any) *c0 = c;
+                any = true;
+                *c1 = c + 1;
+            }
+        };
+        if (t1.n_inner > 0) free_range(1, t1.n_chunks, &t1.free_c0, &t1.free_c1);
+        free_range(0, t1.n_chunks_edge, &t1.free_e0, &t1.free_e1);
+    }
     if (senders) {   // the same test as the kernel's, on the same tilings
         int n = 0;
         if (hw.done)

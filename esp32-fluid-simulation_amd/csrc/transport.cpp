@@ -60,6 +60,7 @@ public:
         SFL_TRY(use_device(c));
         hipStream_t st = on ? on : c->stream;
         const size_t bytes = band_bytes(c, b);
+        if (self) HIP_TRY(launch_spin_us(st, c->opt_emulate_wire_us));   // (a rank talking to itself has no wire: SFL_OPT_EMULATE_WIRE_US adds one)
         NCCL_TRY(ncclGroupStart());
         if (c->rank > 0) {
             NCCL_TRY(ncclSend(row_ptr(c, b.field, c->g0 + b.skip), bytes, ncclChar, peer(c->rank - 1), comm, st));
@@ -352,6 +353,92 @@ int streams_run_concurrently(sfl_context *ctx, bool *yes)
     return SFL_OK;
 }
 
+// kReps exchanges of `rows_a` rows of p, then kReps of `rows_b`, each one handed over from and to the compute stream BY THE
+// PROTOCOL THE NEXT SOLVE WILL USE, timed by events on the compute stream: what an exchange costs a stream that has to wait
+// for it.  Behind events: an event in front of the message, one behind it.  Counted on the device: a one-wave kernel on the
+// compute stream stands in for the launch whose sender tiles count themselves, the exchange stream waits for that count,
+// moves the message and raises the arrival count, a one-wave kernel on the compute stream stands in for the launch whose
+// cut-adjacent tiles wait for it.  (Back-to-back messages on the exchange stream alone pipeline their launches and show a
+// third of the cost: 10 us for RCCL's send / receive pair where a solve pays 17 more than for a copy; the event hand-overs
+// cost 18 us that the counted protocol does not pay.)  latency = what a message of no rows would cost, per_row = the slope.
+// The ghost rows of p are overwritten (nobody relies on them between solves: p_ghost_valid is cleared).
+int measure_exchange(sfl_context *ctx)
+{
+    std::vector<sfl_context *> peers = peers_of(ctx);
+    Transport *t = ctx->transport.get();
+    if (!t || ctx->nranks < 2) return SFL_OK;
+    const int deepest = std::min(kLegacySorHalo, min_owned_rows(ctx));
+    const int rows_a = std::max(1, deepest / 8), rows_b = deepest;
+    constexpr int kReps = 20;
+    for (sfl_context *c : peers) {
+        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+        c->p_ghost_valid = 0;
+    }
+    Overlap o;
+    SFL_TRY(overlap_of(ctx, &o));
+    SFL_TRY(use_device(ctx));
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    for (hipEvent_t &e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = SFL_OK;
+    float ms_a = 0.0f, ms_b = 0.0f;
+    do {
+        const bool counted = in_time_exchanges(ctx);
+        auto one = [&](int rows) {
+            if (!counted) {
+                int r = start_exchange(peers, o, SFL_FIELD_PRESSURE, rows);
+                return r == SFL_OK ? await_exchange(peers, o) : r;
+            }
+            for (sfl_context *c : peers) {
+                ++c->done_target;
+                if (launch_signal_arrival(o.compute, c->d_done, c->done_target) != hipSuccess) return fail(SFL_ERR_HIP, "exchange measurement: launch failed");
+            }
+            int r = exchange(peers, SFL_FIELD_PRESSURE, rows, o.xstream, 0, true, true);
+            for (sfl_context *c : peers)
+                if (r == SFL_OK && launch_wait_count(o.compute, c->d_arrival, c->arrival_epoch, c->d_arrival + 1, halo_timeout_us(c)) != hipSuccess)
+                    r = fail(SFL_ERR_HIP, "exchange measurement: launch failed");
+            return r;
+        };
+        for (int k = 0; k < 3 && rc == SFL_OK; ++k) rc = one(rows_b);   // warm-up
+        if (rc != SFL_OK) break;
+        (void)hipEventRecord(ev[0], o.compute);
+        for (int k = 0; k < kReps && rc == SFL_OK; ++k) rc = one(rows_a);
+        (void)hipEventRecord(ev[1], o.compute);
+        for (int k = 0; k < kReps && rc == SFL_OK; ++k) rc = one(rows_b);
+        (void)hipEventRecord(ev[2], o.compute);
+        if (rc != SFL_OK) break;
+        hipError_t e = hipEventSynchronize(ev[2]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_a, ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_b, ev[1], ev[2]);
+        if (e != hipSuccess) rc = fail(SFL_ERR_HIP, "exchange measurement: %s", hipGetErrorString(e));
+    } while (false);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (sfl_context *c : peers) c->last_exchanges = 0;
+    SFL_TRY(rc);
+    const double us_a = ms_a * 1e3 / kReps, us_b = ms_b * 1e3 / kReps;
+    double per_row_ns = rows_b > rows_a ? (us_b - us_a) * 1e3 / (rows_b - rows_a) : 0.0;
+    if (per_row_ns < 0.0) per_row_ns = 0.0;
+    double lat = us_a - rows_a * per_row_ns * 1e-3;
+    if (lat < 1.0) lat = 1.0;
+    // (the slope is quoted per row of 8192 four-byte cells, so that grids of other widths compare)
+    int words[2] = {(int)(lat + 0.5), (int)(per_row_ns * 8192.0 / ctx->dim_x + 0.5)};
+    if (reduces_on_device(ctx)) {   // the maximum over the ranks: every rank must derive the same plan from it
+        int *dev = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), sizeof words));
+        hipError_t e = hipMemcpy(dev, words, sizeof words, hipMemcpyHostToDevice);
+        int rr = e == hipSuccess ? t->allreduce_max(ctx, dev, 2, o.xstream) : fail(SFL_ERR_HIP, "exchange measurement: %s", hipGetErrorString(e));
+        if (rr == SFL_OK && (hipStreamSynchronize(o.xstream) != hipSuccess ||
+                             hipMemcpy(words, dev, sizeof words, hipMemcpyDeviceToHost) != hipSuccess))
+            rr = fail(SFL_ERR_HIP, "exchange measurement: reduction over the ranks failed");
+        (void)hipFree(dev);
+        SFL_TRY(rr);
+    }
+    for (sfl_context *c : peers) {
+        c->exchange_latency_us = words[0];
+        c->exchange_ns_per_row = words[1];
+    }
+    return SFL_OK;
+}
+
 }  // namespace host
 }  // namespace sfl
 
@@ -449,6 +536,7 @@ static int attach_rccl(sfl_context *c, const ncclUniqueId &uid, bool self)
     bool side_by_side = false;
     int rc = streams_run_concurrently(c, &side_by_side);
     if (rc == SFL_OK) rc = sfl_comm_check_options(c);
+    if (rc == SFL_OK) rc = measure_exchange(c);   // (collective: every rank exchanges with its neighbours; after the option check)
     if (rc != SFL_OK) {
         const std::string why = last_error();
         c->transport.reset();

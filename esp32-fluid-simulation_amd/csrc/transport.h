@@ -63,6 +63,7 @@ public:
     hipStream_t chain_stream[kSideChains] = {nullptr, nullptr};
     hipEvent_t ev_chain[kSideChains] = {nullptr, nullptr};
     int streams_concurrent = -1;   // as sfl_context::streams_concurrent, for the group's pair of streams
+    HaloTuner halo_tuner;          // as sfl_context::halo_tuner, for the group's solves
     ~Group() override;
     int kind() const override { return 2; }
     int move(const std::vector<sfl_context *> &peers, const HaloBands &b, hipStream_t on) override;
@@ -110,6 +111,11 @@ int reduce_max_then_copy(sfl_context *ctx, int *dev_words, int n, int *host_word
 // Do the compute and the exchange stream of this context run side by side?  (A launch that waits for a message inside the
 // kernel would otherwise sit in front of the kernels that deliver it.)  Measured once per context / group, cached.
 int streams_run_concurrently(sfl_context *ctx, bool *yes);
+// What does one halo exchange of this context's transport cost?  Times back-to-back exchanges of p at two depths on the
+// exchange stream (the protocol a solve uses, nothing else running), fits latency + per-row cost, takes the maximum over
+// the ranks and stores it in every context of peers_of(ctx) (exchange_latency_us, exchange_ns_per_row).  Collective on
+// RCCL ranks: called at attach there, before the first solve elsewhere.
+int measure_exchange(sfl_context *ctx);
 
 }  // namespace host
 }  // namespace sfl

@@ -67,6 +67,28 @@ def plan_poisson(dim_y: int, nranks: int, rank: int, iters: int, fuse: int = 8, 
     return [steps[k] for k in range(n.value)]
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on the C library's stdout while a communicator comes up (buffered: it would surface when
+    the process exits).  A program whose stdout carries ONE JSON line wraps communicator creation in this: file descriptor 1
+    points at stderr for the duration, and the C library's buffers are flushed before it is restored."""
+
+    def __enter__(self):
+        import os
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        try:
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+
+
 def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
     capi.check(capi.lib().sfl_comm_unique_id(buf, capi.UNIQUE_ID_BYTES))
@@ -227,7 +249,7 @@ class Solver:
     def last_solve_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         capi.check(self._lib.sfl_last_solve_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"launches": a.value, "exchanges": b.value, "fuse": c.value}
+        return {"launches": a.value, "exchanges": b.value, "fuse": c.value, "halo": self.get_option(capi.OPT_LAST_HALO)}
 
 
 def _fp(a):

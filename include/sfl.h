@@ -81,9 +81,13 @@ extern "C" {
 #define SFL_OPT_SOR_LANE_CELLS 5  /* cells per lane of kernel 2: 0 = auto or 2 (the only flavour
                                      left: round 1's packed 4-cell tiles were never faster)        */
 #define SFL_OPT_SOR_HALO 6        /* rows of p a superstep's halo makes valid on a slab (kernel 2): 0 =
-                                     auto (64 on slabs of >= 1024 rows, else 32), else fuse..64;
-                                     larger = fewer, larger exchanges, more recomputed ghost rows; from
-                                     2 x fuse on the exchanges are issued one launch early (sfl_plan_poisson) */
+                                     auto, else fuse..160; larger = fewer, larger exchanges, more recomputed
+                                     ghost rows; from 2 x fuse on, exchanges behind events are issued one launch
+                                     early (sfl_plan_poisson).  Auto starts from 64 rows on slabs of >= 1024 rows
+                                     (32 on thinner ones) and moves to another depth when a model of the solve --
+                                     redundant rows against exchanges at their MEASURED cost,
+                                     SFL_OPT_MEASURED_WIRE_US -- predicts at least 3 % (SFL_OPT_LAST_HALO reads
+                                     what a solve used)                                                    */
 #define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied
                                      inside the dye-advection kernel (one pass over v), 0 = two
                                      kernels                                                     */
@@ -107,7 +111,7 @@ extern "C" {
                                      sfl_step run as ONE launch of one workgroup with the fields in
                                      LDS (the sketch's 61 x 81 grid: one launch instead of six to
                                      ten); 0 = the general kernels                                 */
-#define SFL_OPT_EMULATE_WIRE_US 12 /* sfl_comm_emulate only (measurement aid): every emulated halo message is held
+#define SFL_OPT_EMULATE_WIRE_US 12 /* sfl_comm_emulate / sfl_comm_emulate_rccl only (measurement aid): every emulated halo message is held
                                      back by this many microseconds on the exchange stream before its copy
                                      starts -- the latency of a real xGMI send / receive that a self-copy does
                                      not have; 0 (default) .. 10000                                   */
@@ -152,6 +156,14 @@ extern "C" {
 #define SFL_OPT_EXCHANGE_SCHEDULE 19 /* READ ONLY: how the next solve on this slab will order its halo exchanges: 0 = none to
                                      order (whole domain, no transport, the baseline kernel), 1 = in line, 2 = one launch early
                                      behind cross-stream events, 3 = in time, counted on the device                        */
+#define SFL_OPT_MEASURED_WIRE_US 20  /* READ ONLY: slabs with a transport: microseconds one halo exchange of this context costs before
+                                     its first byte moves (launches, protocol, wire), measured -- not assumed -- with
+                                     back-to-back exchanges of p at two depths when the transport was attached (RCCL ranks:
+                                     the maximum over the ranks) or on first demand (virtual / emulated ranks: the copy, and
+                                     SFL_OPT_EMULATE_WIRE_US if set); -1 = nothing to measure.  The automatic halo depth of a
+                                     solve (SFL_OPT_SOR_HALO = 0) is chosen from it: deeper halos = fewer exchanges, more rows
+                                     relaxed redundantly                                                             */
+#define SFL_OPT_LAST_HALO 21         /* READ ONLY: halo depth (rows of p per superstep) of the last solve's plan on this slab  */
 
 typedef struct sfl_context sfl_context;
 

@@ -21,8 +21,8 @@ def plan_exchanges(sfl, dim_y, nranks, iters, fuse, halo=0, kernel=3):
     counted on the program sfl_plan_poisson returns (csrc/sfl_api.cpp effective_halo restated).  kernel 3 = exchanges in
     time (the default executor, SFL_OPT_SOR_ARRIVAL), 2 = early exchanges where the halo is deep enough."""
     rows = min(b - a for a, b in (sfl.slab_rows(dim_y, nranks, r) for r in range(nranks)))
-    h = halo or (64 if rows >= 1024 else 32)
-    h = max(min(h, rows, 64), fuse)
+    h = halo or (64 if rows >= 1024 else 32)      # (callers pass last_solve_info()["halo"]: the automatic depth is a measured choice)
+    h = max(min(h, rows, 160), fuse)
     return sum(st.kind == sfl.capi.STEP_EXCHANGE for st in sfl.plan_poisson(dim_y, nranks, 0, iters, fuse, kernel, h))
 
 
@@ -535,7 +535,7 @@ def test_virtual_slabs_with_auto_settings_at_realistic_size(sfl, oracle, nranks)
             s.close()
     assert_bit_equal(got, want, f"{nranks} slabs, auto settings")
     assert info["fuse"] == 8 and info["launches"] == 5
-    assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, 8) >= 1   # the rhs once (+ p)
+    assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, 8, info["halo"]) >= 1   # the rhs once (+ p)
 
 
 def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
@@ -559,7 +559,9 @@ def test_virtual_slabs_eight_ranks_on_the_headline_grid(sfl, oracle):
         for s in slabs:
             s.close()
     assert_bit_equal(got, want, "8192^2 in 8 slabs, auto settings")
-    assert info["fuse"] == 10 and info["launches"] == 16 and info["exchanges"] == 3 == plan_exchanges(sfl, dim, nranks, iters, 10)
+    # (the halo depth is chosen from the measured exchange: 64 rows = the rhs + two p exchanges, deeper = fewer)
+    assert info["fuse"] == 10 and info["launches"] == 16 and info["halo"] >= 64
+    assert 1 <= info["exchanges"] == plan_exchanges(sfl, dim, nranks, iters, 10, info["halo"]) <= 3
 
 
 @pytest.mark.parametrize("dim_y,fuse", [(1600, 10), (3200, 16)])
@@ -783,7 +785,8 @@ def test_baseline_config5_slab_program_vs_oracle(sfl, oracle):
         for s in slabs:
             s.close()
     # the rhs + six in-time p exchanges (supersteps of four launches: 64 passes per 64-row halo)
-    assert info["fuse"] == 16 and info["launches"] == 25 and info["exchanges"] == 7 == plan_exchanges(sfl, dim_y, nranks, iters, 16)
+    assert info["fuse"] == 16 and info["launches"] == 25 and info["halo"] >= 64
+    assert 1 <= info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, 16, info["halo"]) <= 7
     assert_bit_equal(got, want, "C5 slab program: 16384 x 4096 in two slabs, 200 iterations")
 
 
@@ -1273,7 +1276,7 @@ def test_emulated_rank_runs_its_program_alone(sfl):
         s.synchronize()
         info = s.last_solve_info()
         got = s.download(sfl.capi.FIELD_PRESSURE)
-        assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, info["fuse"]) and info["launches"] == -(-2 * iters // info["fuse"])
+        assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, info["fuse"], info["halo"]) and info["launches"] == -(-2 * iters // info["fuse"])
         # information travels one row per colour pass: 2 * iters rows from each cut are tainted by the fake halos
         reach = 2 * iters
         inner = slice(reach, (s.row_end - s.row_begin) - reach)
@@ -1357,7 +1360,7 @@ def test_emulated_rank_with_rccl_as_transport(sfl, rank, dim_x, dim_y, iters, ar
         got = s.download(sfl.capi.FIELD_PRESSURE)
         in_time = arrival != 0
         assert info["launches"] == -(-2 * iters // info["fuse"])
-        assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, info["fuse"], kernel=3 if in_time else 2)
+        assert info["exchanges"] == plan_exchanges(sfl, dim_y, nranks, iters, info["fuse"], info["halo"], kernel=3 if in_time else 2)
         reach = 2 * iters
         rows = s.row_end - s.row_begin
         inner = slice(reach if rank > 0 else 0, rows - (reach if rank < nranks - 1 else 0))
@@ -1535,7 +1538,7 @@ def test_baseline_config5_in_full_on_eight_virtual_ranks(sfl, oracle):
         for s in slabs:
             s.close()
     assert info["fuse"] == 16 and info["launches"] == 25
-    assert info["exchanges"] == plan_exchanges(sfl, dim, nranks, iters, 16)
+    assert info["exchanges"] == plan_exchanges(sfl, dim, nranks, iters, 16, info["halo"])
 
 
 def test_baseline_config4_whole_sim_step_on_eight_virtual_ranks(sfl, oracle):

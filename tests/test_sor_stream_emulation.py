@@ -29,6 +29,8 @@ def emu():
     lib.emu_tiling_cover.restype = C.c_int
     lib.emu_tiling_deps.argtypes = [C.c_int] * 13
     lib.emu_tiling_deps.restype = C.c_int
+    lib.emu_tile_order.argtypes = [C.c_int] * 13
+    lib.emu_tile_order.restype = C.c_int
 
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
             gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, flip=True):
@@ -162,6 +164,31 @@ def test_dependencies_between_two_tilings(emu):
             assert n >= 0, (ns, dim_x, gdim_y, a0, a1, arpc, b0, b1, brpc, reach, balance)
             total += n
     assert total > 1000
+
+
+def test_dispatch_order_is_a_bijection_with_the_free_tiles_first(emu):
+    """A launch hands out the tiles that will wait for a halo message inside the kernel LAST (sor::tile_of_position: otherwise
+    the first XCD fills up with waiting tiles and the kernel that delivers the message finds no room there).  The order is
+    scheduling only -- but it must visit every tile exactly once, whatever chunk ranges the launcher marks free: the thin-slab
+    and whole-grid shapes of the BASELINE configurations and random ones, with ranges that are empty, full, or partial."""
+    rng = np.random.default_rng(5)
+    cases = [(10, 8192, 8192, 960, 2112, 41), (16, 16384, 16384, 5984, 8352, 100), (16, 8192, 8192, 0, 8192, 234),
+             (8, 300, 200, 0, 200, 30), (10, 130, 900, 100, 800, 9)]
+    for _ in range(300):
+        ns = int(rng.choice([2, 4, 8, 10, 12, 16]))
+        dim_x, gdim_y = int(rng.integers(2, 1200)), int(rng.integers(2, 700))
+        b = int(rng.integers(0, gdim_y))
+        e = int(rng.integers(b + 1, gdim_y + 1))
+        cases.append((ns, dim_x, gdim_y, b, e, int(rng.integers(1, e - b + 1))))
+    total = 0
+    for ns, dim_x, gdim_y, b, e, rpc in cases:
+        for balance in (0, 10):
+            for _ in range(6):
+                c0, c1, e0, e1 = (int(v) for v in rng.integers(-2, 40, 4))
+                n = emu.lib.emu_tile_order(ns, 128, 2, dim_x, gdim_y, b, e, rpc, balance, c0, c1, e0, e1)
+                assert n > 0, (ns, dim_x, gdim_y, b, e, rpc, balance, c0, c1, e0, e1)
+                total += n
+    assert total > 100000
 
 
 @pytest.mark.parametrize("ns", [2, 4, 8, 10, 12, 16])

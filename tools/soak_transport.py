@@ -54,13 +54,8 @@ while time.time() - t0 < budget or solves < min_solves:
     inner = slice(reach if rank > 0 else 0, rows - (reach if rank < nranks - 1 else 0))
     with sfl.Solver(dim_x, dim_y, 0, rank, nranks) as s:
         if transport == "rccl":
-            saved = os.dup(1)      # RCCL's banner
-            os.dup2(2, 1)
-            try:
+            with sfl.stdout_to_stderr():      # RCCL's banner
                 s.comm_emulate_rccl()
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
         else:
             s.comm_emulate()
         s.set_option(capi.OPT_SOR_FUSE, fuse)
