@@ -719,6 +719,7 @@ def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
     try:
         sfl.Solver.link_group(slabs)
         slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 10)
+        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, 32)     # (the automatic depth is a timed choice: this test wants its exchanges)
         assert slabs[3].get_option(sfl.capi.OPT_SOR_ARRIVAL) == -1 and slabs[3].get_option(sfl.capi.OPT_EXCHANGE_SCHEDULE) == 3   # automatic: in time
         for rep in range(3):
             slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, 0 if rep == 1 else 1)   # (early exchanges behind events in the middle repetition)
