@@ -585,6 +585,9 @@ __device__ __forceinline__ float2 sample_global_projected(const float2 *v, const
 
 // 512 threads; the register allocator leaves room for 6 waves per SIMD = three blocks per CU (80 VGPRs; two blocks at the 86 it
 // would take by itself: 836 against 780 us; four blocks at 64 VGPRs spill: 1390 us)
+#ifndef SEAM_DYE_LOADS
+#define SEAM_DYE_LOADS 0   // where the dye window's loads are issued: 0 = behind the velocity's advection, 1 = in front of it (A/B)
+#endif
 constexpr int kThreadsSeam = 512;
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS, 6)
@@ -630,11 +633,6 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
             got_v[k] = window_has<kDX>(wv, e) ? v[window_cell<kDX>(wv, g, e)] : float2{0.0f, 0.0f};
         }
 #pragma unroll
-        for (int k = 0; k < kLoadsC; ++k) {
-            const int e = threadIdx.x + k * THREADS;
-            got_c[k] = window_has<kSX>(wc, e) ? load_uq3(col, window_cell<kSX>(wc, g, e)) : uq3{0u, 0u, 0u};
-        }
-#pragma unroll
         for (int k = 0; k < kLoadsP; ++k) {
             const int e = threadIdx.x + k * THREADS;
             if (e < kPX * kPY) lds_p[e] = got_p[k];
@@ -656,6 +654,13 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
         }
     }
     __syncthreads();
+#if SEAM_DYE_LOADS == 1
+#pragma unroll
+    for (int k = 0; k < kLoadsC; ++k) {
+        const int e = threadIdx.x + k * THREADS;
+        got_c[k] = window_has<kSX>(wc, e) ? load_uq3(col, window_cell<kSX>(wc, g, e)) : uq3{0u, 0u, 0u};
+    }
+#endif
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = x0 + lane;
@@ -696,6 +701,17 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
     const bool ring = ri >= 0 && ri < g.dim_x && rj >= 0 && rj < g.gdim_y;
     float2 around = float2{0.0f, 0.0f};
     if (ring) around = advected(ri, rj);
+    // The dye window is not needed before this point, and its 18 registers per thread are what pushed the kernel over the
+    // 80 VGPRs that let three blocks share a CU: with every load of the block up front it spilled 9 registers (16 B of
+    // scratch per thread = the 203 MB of writes nobody could explain in profiles/r04_sim_step_summary.txt).  Its loads are
+    // issued HERE; the other two blocks of the CU cover their latency.
+#if SEAM_DYE_LOADS == 0
+#pragma unroll
+    for (int k = 0; k < kLoadsC; ++k) {
+        const int e = threadIdx.x + k * THREADS;
+        got_c[k] = window_has<kSX>(wc, e) ? load_uq3(col, window_cell<kSX>(wc, g, e)) : uq3{0u, 0u, 0u};
+    }
+#endif
     __syncthreads();   // everybody is done with the velocity window: the dye window moves in
 #pragma unroll
     for (int k = 0; k < kLoadsC; ++k) {

@@ -26,17 +26,22 @@ def short(name):
     import re
     # sor_fused_kernel<Lane2<NS, VEC, ZERO_IN[, NT]> | Lane4<NS, ZERO_IN>, NS, DX1, ZERO_IN>
     # (the store policy ST is an int since round 4 -- 0 plain, 2 nt, 16 sc1 -- and was a bool NT before)
-    m = re.search(r"sor_fused_kernel<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)(?:, (\d+))?>, \d+, (true|false), (true|false)>", name)
+    # (... and a load policy LD since the chained launch: Lane2<NS, VEC, ZERO_IN, ST, LD>.  Every template argument that tells two
+    # instantiations apart is kept: NS, dx1, zero_in and the cache policies -- VERDICT r04: a truncated name had merged the
+    # zero_in = true and zero_in = false kernels into one row)
+    m = re.search(r"(sor_fused_kernel|sor_chain_kernel)<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)((?:, \d+)*)>, \d+, (true|false)(?:, (true|false))?>", name)
     if m:
-        flags = [f == "true" for f in re.findall(r"true|false", m.group(3))]
-        st = {"2": "nt", "16": "sc1"}.get(m.group(4) or "", "nt" if (m.group(1) == "2" and len(flags) >= 3 and flags[2]) else "")
-        return (f"sor_fused_kernel<Lane{m.group(1)}{st}, NS={m.group(2)}, dx1={m.group(5)}, "
-                f"zero_in={m.group(6)}>")
+        flags = [f == "true" for f in re.findall(r"true|false", m.group(4))]
+        pol = re.findall(r"\d+", m.group(5))
+        st = {"2": "nt", "16": "sc1"}.get(pol[0] if pol else "", "nt" if (m.group(2) == "2" and len(flags) >= 3 and flags[2]) else "")
+        ld = {"16": "+ldsc1"}.get(pol[1] if len(pol) > 1 else "", "")
+        zero = f", zero_in={m.group(7)}" if m.group(7) else ""
+        return f"{m.group(1)}<Lane{m.group(2)}{st}{ld}, NS={m.group(3)}, dx1={m.group(6)}{zero}>"
     m = re.search(r"(advect_divergence_tiled_kernel|advect_vec2f_tiled_kernel|advect_vec3uq32_tiled_kernel)<([^>]*)>", name)
     if m:
         flags = re.findall(r"true|false", m.group(2))
         label = {"advect_divergence_tiled_kernel": ["no_slip"], "advect_vec2f_tiled_kernel": ["no_slip", "self"],
-                 "advect_vec3uq32_tiled_kernel": ["no_slip", "fuse_grad"]}[m.group(1)]
+                 "advect_vec3uq32_tiled_kernel": ["no_slip", "fuse_grad", "reach"]}[m.group(1)]
         return m.group(1) + "<" + ", ".join(f"{a}={b}" for a, b in zip(label, flags)) + ">"
     for key in ("seam_tiled_kernel", "advect_channels_kernel", "copy_bands_kernel", "signal_arrival_kernel"):
         if key in name:
@@ -48,7 +53,11 @@ def short(name):
                 "divergence_kernel", "subtract_gradient_kernel", "zero_rows_kernel", "apply_forces_kernel"):
         if key in name:
             return key
-    return name[:70]
+    # anything else: the demangled name without its argument list, template arguments kept (abbreviated, never cut off in
+    # the middle of what distinguishes two kernels)
+    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\b(void|sfl::|\(anonymous namespace\)::)", "", name).strip()
+    return name if len(name) <= 110 else name[:107] + "..."
 
 
 print(f"# profile summary of {os.path.basename(root)}")
@@ -58,10 +67,10 @@ for f in sorted(glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv")
     for row in rows:
         dur[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     print("\n## kernel trace (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, root))
-    print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s} | steady state (last n): {'n':>5s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+    print(f"{'kernel':90s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s} | steady state (last n): {'n':>5s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         t = tail_of(v)
-        print(f"{k:70s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f} | "
+        print(f"{k:90s} {len(v):6d} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {max(v)/1e3:10.2f} {sum(v)/1e6:10.3f} | "
               f"{'':23s}{len(t):5d} {sum(t)/len(t)/1e3:10.2f} {min(t)/1e3:10.2f} {max(t)/1e3:10.2f}")
 
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
@@ -84,4 +93,4 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
                     extra = f"  -> {avg * 1024 * 2 / 1e6:.1f} MB/launch read (x2 gfx950 correction), raw {avg * 1024 / 1e6:.1f} MB"
                 if c == "WRITE_SIZE":
                     extra = f"  -> {avg * 1024 / 1e6:.1f} MB/launch written (uncalibrated)"
-                print(f"{k:70s} {c:28s} n={len(v):4d} avg={avg:16.1f}{extra}")
+                print(f"{k:90s} {c:28s} n={len(v):4d} avg={avg:16.1f}{extra}")
