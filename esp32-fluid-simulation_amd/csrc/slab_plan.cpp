@@ -61,6 +61,8 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
     // exchanged after every launch (messages are latency-bound, so the lever is the
     // exchange COUNT).  The first superstep needs no exchange: p is zero everywhere.
     const std::vector<int> passes = sor_pass_plan(iters, fuse);
+    if (passes.empty()) return prog;   // iters == 0: nothing to launch, nothing to exchange (the early-exchange branch below
+                                       // indexed its empty tables at n - 1: found by UBSan, tests/cpp/host_san_driver.cpp)
     if (halo < fuse) halo = fuse;
 
     // kernel 3 = kernel 2's launches with IN-TIME exchanges at every halo depth: the halo of a superstep is sent after the

@@ -309,7 +309,41 @@ struct Lane2 : WaveCommon {
     // multiply by the tiles the scheme would save.
     float *coop_pub, *coop_get;   // this lane's publish / pick-up word in the block's exchange area
     bool coop_is_pub, coop_is_ghost;
-#if SFL_PROBE_COOP == 2
+#if SFL_PROBE_COOP == 3
+    // TIMING MOCK of a two-wave VERTICAL pass pipeline (VERDICT r04 item 5 b): wave A of a pair would run passes 1 .. NS/2 and
+    // hand every finished row to wave B (passes NS/2 + 1 .. NS) through an LDS ring with a row-granular flag -- no
+    // s_barrier.  Here the waves of a pair are neighbouring tiles of the shipped tiling that do exactly that traffic, with
+    // the real dependency: the even wave writes a row (ds_write_b64 per lane) into an 8-row ring, drains, publishes its row
+    // count and stays at most 6 rows ahead of its partner (one ds_read_b32 per row); the odd wave waits for the count, takes
+    // the row from the ring INTO ITS PIPELINE (the row that enters is what it read: garbage results) and publishes its own
+    // progress.  Compare the time per launch with the shipped kernel's: the difference is what the hand-over costs a row.
+    float *vp_ring;                    // this lane's two words in row slot 0 of the pair's ring
+    int *vp_mine, *vp_other;           // rows this wave / its partner has gone through
+    int vp_rows;
+    bool vp_producer;
+    template <int NSW, int U, class P>
+    __device__ __forceinline__ void coop_mock(P &pp)
+    {
+        constexpr int RING = sor::ring_rows(NSW);
+        constexpr int Q = U % kPrefetch;
+        ++vp_rows;
+        float2 *slot = reinterpret_cast<float2 *>(vp_ring + (vp_rows & 7) * 128);
+        if (vp_producer) {
+            for (int spin = 0; spin < 4000 && vp_rows - __hip_atomic_load(vp_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 6; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+            *slot = float2{pp.E[sor::wrapn(U - 1, RING)], pp.O[sor::wrapn(U - 2, RING)]};
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the row is in LDS before the count says so
+            __hip_atomic_store(vp_mine, vp_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            for (int spin = 0; spin < 4000 && __hip_atomic_load(vp_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < vp_rows; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+            const float2 got = *slot;
+            pp.pa[Q] = got.x;
+            pp.pb[Q] = got.y;
+            __hip_atomic_store(vp_mine, vp_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+#elif SFL_PROBE_COOP == 2
     static __device__ __forceinline__ unsigned lds_addr(float *p)
     {
         return (unsigned)(size_t)(__attribute__((address_space(3))) float *)p;
@@ -468,6 +502,16 @@ __device__ __forceinline__ int relax_tile(float *p_out, const float *p_in, const
         bk.prio_on = sender ? 2 : t.rotate;   // senders first: the message is waiting for them
         bk.start_turns();
         bk.setup(ring_base, lane, x0, t.halo_cols);
+#if defined(SFL_PROBE_COOP) && SFL_PROBE_COOP == 3
+        {
+            float *pair = coop_mem + (wave >> 1) * (8 * 128 + 16);
+            bk.vp_ring = pair + lane * 2;
+            bk.vp_mine = reinterpret_cast<int *>(pair + 8 * 128) + (wave & 1);
+            bk.vp_other = reinterpret_cast<int *>(pair + 8 * 128) + 1 - (wave & 1);
+            bk.vp_rows = 0;
+            bk.vp_producer = (wave & 1) == 0;
+        }
+#endif
 #ifdef SFL_PROBE_COOP
         bk.coop_is_pub = lane == 1 || lane == 62;
         bk.coop_is_ghost = lane == 0 || lane == 63;
@@ -506,7 +550,11 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
                  sor::Tiling t2, SorParams prm, HaloWait hw)
 {
     __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
-#ifdef SFL_PROBE_COOP
+#if defined(SFL_PROBE_COOP) && SFL_PROBE_COOP == 3
+    __shared__ float coop_mem[2 * (8 * 128 + 16)];   // per pair of waves: an 8-row ring of 64 x 2 words + the two row counts
+    for (int k = threadIdx.x; k < 2 * (8 * 128 + 16); k += kThreads) coop_mem[k] = 0.0f;
+    __syncthreads();
+#elif defined(SFL_PROBE_COOP)
     __shared__ float coop_mem[2 * NS * 8];   // [row parity][value][wave x {left edge, right edge}]
 #endif
 
