@@ -639,7 +639,7 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
         }
         __syncthreads();
         // ino:276 on the velocity window: every thread projects the cells it loaded, pressure from LDS (five scattered loads
-        // per window cell from memory cost 300 of the kernel's 970 us: tools/r04/run13.sh)
+        // per window cell from memory cost 300 of the kernel's 970 us: profiles/r04_step_seam.txt)
 #pragma unroll
         for (int k = 0; k < kLoadsV; ++k) {
             const int e = threadIdx.x + k * THREADS;

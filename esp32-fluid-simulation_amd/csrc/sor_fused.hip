@@ -601,7 +601,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // bytes of an owned row also holds the last bytes of the ghost row below it.  A tile that does NOT wait must not touch such
     // a line either: its fill, requested before the message landed, can be installed in the CU's L1 after a waiting tile's
     // acquire has invalidated it, and the waiting tile then reads the ghost row's old bytes from it (seen once in 26 k solves
-    // on 3000- and 2999-column slabs, never on pitches of whole lines: tools/r04/unaligned_stress.py).  Hence `line_rows`.
+    // on 3000- and 2999-column slabs, never on pitches of whole lines: tools/unaligned_stress.py).  Hence `line_rows`.
     const int line_rows = (g.dim_x & 63) ? 1 + 63 / g.dim_x : 0;   // rows a 256-byte span reaches across a row boundary
     const int reach = NS + sor::ring_rows(NS) + line_rows;
     if (hw.flag != nullptr && (r0 - reach < hw.own_lo || r1 + reach > hw.own_hi)) {  // wave-uniform

@@ -2,7 +2,8 @@
 # First thing to run on a node with more than one MI355X: the RCCL path with N > 1 has only ever been
 # exercised on one-GPU boxes (virtual ranks, an emulated rank, a one-rank communicator).
 #   1. the multi-GPU tests (BASELINE configs 4 and 5 exactly, 2- and 4-rank points, with and without overlap);
-#   2. bench.py at 1 / 2 / 4 / 8 GPUs: exchanges in time, the same inside chained launches where the slabs are thin
+#   2. bench.py at 1 / 2 / 4 / 8 GPUs: the launcher's own chain of schedules (in time -> behind events -> in line, fresh ranks per
+#      attempt), then every schedule forced: exchanges in time, the same inside chained launches where the slabs are thin
 #      (--chain -1), early exchanges behind events, in line --
 #      the ranks are started as fresh child processes by bench.py's own launcher (its parent never touches a GPU);
 #   3. RCCL's own report of the ranks (NCCL_DEBUG=INFO of the 2-GPU run: "comm ... nranks 2" per rank);
@@ -20,19 +21,23 @@ if [ "$NG" -lt 2 ]; then echo "needs at least 2 GPUs" | tee -a $O/summary.txt; e
 tail -3 $O/pytest_multi_gpu.log | tee -a $O/summary.txt
 for n in 1 2 4 8; do
   [ $n -le $NG ] || continue
-  for mode in "" "--chain -1" "--arrival-by-event" "--no-overlap"; do
+  # "" = the launcher's own chain: exchanges in time first, then -- with FRESH ranks -- behind events, then in line; the line's
+  # exchange_mode / fallback_from say which schedule produced it.  The others force one schedule (no fallback).
+  for mode in "" "--arrival-in-time" "--arrival-in-time --chain -1" "--arrival-by-event" "--no-overlap"; do
     tag=n${n}$(echo "$mode" | tr -d ' -')
     timeout 900 python3 bench.py --gpus $n --steps 10 --warmup 3 $mode > $O/bench_$tag.json 2> $O/bench_$tag.err || tail -3 $O/bench_$tag.err
     python3 -c "
 import json; d = json.load(open('$O/bench_$tag.json'))
-print('%-34s %d GPU(s): %.3e cell-iters/s  %.4f ms per solve  %s sim steps/s  parity %s  exchanges per solve %s' % ('${mode:-in time}', d['n_gpus'], d['value'], d['ms_per_step'], d['sim_steps_per_sec'], (d.get('parity') or {}).get('bit_exact'), d['config']['halo_exchanges_per_solve']))" | tee -a $O/summary.txt
+print('%-34s %d GPU(s): %.3e cell-iters/s  %.4f ms per solve  %s sim steps/s  parity %s  exchanges per solve %s  halo %s rows  measured exchange %s us  schedule %s  fallback_from %s' % ('${mode:-launcher chain}', d['n_gpus'], d['value'], d['ms_per_step'], d['sim_steps_per_sec'], (d.get('parity') or {}).get('bit_exact'), d['config']['halo_exchanges_per_solve'], d['config'].get('halo_rows_per_superstep'), d['config'].get('measured_exchange_latency_us'), d.get('exchange_mode', d['config'].get('exchange_schedule')), [f.get('mode') for f in d.get('fallback_from', [])]))" | tee -a $O/summary.txt
   done
 done
 NCCL_DEBUG=INFO timeout 600 python3 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --sim-steps 0 > /dev/null 2> $O/rccl_info_n2.log
 grep -c "nranks 2" $O/rccl_info_n2.log | sed 's/^/RCCL communicators reporting nranks 2: /' | tee -a $O/summary.txt
 N=$NG; [ $N -gt 8 ] && N=8
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29531 --no-python \
+# (SFL_BENCH_WORKER=1: every process torch.distributed.run starts IS a rank -- without it bench.py would be its rank's supervisor and
+# do the GPU work in a child the profiler does not follow)
+SFL_BENCH_WORKER=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29531 --no-python \
     rocprofv3 --kernel-trace --output-format csv -d $O/trace_n$N -o t -- python3 bench.py --gpus $N --steps 6 --warmup 3 --no-priming --no-cpu-baseline --sim-steps 0 \
     > $O/trace_n$N.log 2>&1 || tail -3 $O/trace_n$N.log
-for f in $(find $O/trace_n$N -name "*kernel_trace.csv" | head -2); do python3 tools/r03/timeline.py $f > ${f%.csv}_timeline.txt 2>/dev/null; done
+for f in $(find $O/trace_n$N -name "*kernel_trace.csv" | head -2); do python3 tools/timeline.py $f > ${f%.csv}_timeline.txt 2>/dev/null; done
 cat $O/summary.txt

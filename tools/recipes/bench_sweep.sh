@@ -1,6 +1,6 @@
 #!/bin/bash
 # One parametrised bench sweep (replaces round 2's 47 one-shot tools/r02_runs/r02_run*.sh, which are in the git
-# history up to commit 99421be).  Runs ON THE GPU BOX:  gpurun -- 'bash tools/bench_sweep.sh <tag> <common args> -- <variant> [-- <variant> ...]'
+# history up to commit 99421be).  Runs ON THE GPU BOX:  gpurun -- 'bash tools/recipes/bench_sweep.sh <tag> <common args> -- <variant> [-- <variant> ...]'
 #   tag            results go to gpurun_out/sweep_<tag>.txt
 #   common args    passed to every bench.py run (e.g. --steps 30 --warmup 5 --no-cpu-baseline --sim-steps 0)
 #   variant        extra bench.py arguments of one run; an item LIB=<path> selects another build of the library
@@ -19,7 +19,10 @@ for rep in 1 2; do
   for v in "${VARIANTS[@]}"; do
     lib=""; args=""
     for w in $v; do case $w in LIB=*) lib=${w#LIB=};; *) args="$args $w";; esac; done
-    SFL_LIB=$lib python bench.py "${COMMON[@]}" $args > gpurun_out/sweep_$TAG.json 2> gpurun_out/sweep_$TAG.err || { echo "FAILED:$v" | tee -a $OUT; tail -3 gpurun_out/sweep_$TAG.err; continue; }
+    # (another build of the library -- tools/recipes/build_variant.sh -- is selected through tools/with_lib.py: the product binding
+    # knows one path only, and an SFL_LIB variable it ignores would silently benchmark the product library: ADVICE r04)
+    if [ -n "$lib" ]; then run=(python tools/with_lib.py "$lib" bench.py); else run=(python bench.py); fi
+    "${run[@]}" "${COMMON[@]}" $args > gpurun_out/sweep_$TAG.json 2> gpurun_out/sweep_$TAG.err || { echo "FAILED:$v" | tee -a $OUT; tail -3 gpurun_out/sweep_$TAG.err; continue; }
     python - "$v" gpurun_out/sweep_$TAG.json <<'PY' | tee -a $OUT
 import json, sys
 d = json.load(open(sys.argv[2]))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K whole sim steps on four virtual ranks (8192 x 2048 domain, automatic advection halo, every option default) and
 nothing else between the two markers -- run under `rocprofv3 --hip-trace` twice (K = 5, K = 25): the difference of the
-HIP API call counts divided by 20 is what ONE step issues (tools/r03/step_api_trace.sh)."""
+HIP API call counts divided by 20 is what ONE step issues (rocprofv3 --hip-trace --stats -- python3 tools/step_api_probe.py)."""
 import importlib
 import os
 import sys

@@ -21,6 +21,9 @@ if __name__ == "__main__":
     if not os.path.exists(lib):
         sys.exit(f"with_lib.py: {lib} does not exist")
     capi = importlib.import_module("esp32-fluid-simulation_amd._capi")
+    assert capi._lib is None, "with_lib.py: the product library is already loaded (something loaded it at import time)"
     capi.LIB_PATH = lib
+    loaded = capi.lib()
+    assert os.path.samefile(loaded._name, lib), f"with_lib.py: loaded {loaded._name}, asked for {lib}"
     sys.argv = [script] + sys.argv[3:]
     runpy.run_path(os.path.join(ROOT, script) if not os.path.isabs(script) else script, run_name="__main__")
