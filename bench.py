@@ -200,7 +200,7 @@ def kernel_source_hash():
     another version of them are not this kernel's."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sor_fused.hip", "sor_stream_core.h"):
+    for name in ("sor_fused.hip", "sor_lane.h", "sor_chain.h", "sor_stream_core.h"):
         with open(os.path.join(ROOT, PKG, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -226,7 +226,7 @@ def step_kernel_source_hash():
     """sha256 (first 16 hex digits) of the sources the step's kernels outside the solve are compiled from."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("advect_tiled.hip", "stencil_kernels.hip", "advect_math.h"):
+    for name in ("advect_tiled.hip", "advect_seam.h", "stencil_kernels.hip", "advect_math.h"):
         with open(os.path.join(ROOT, PKG, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -903,11 +903,16 @@ def run_rank(args):
         roofline = {
             "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": hbm_gbs / HBM_PEAK_GBS,
+            # the same with the COMPULSORY bytes only -- p in, rhs in, p out: 12 B per cell and launch; what `frac` has on top of
+            # it are the halo rows and columns neighbouring tiles re-read
+            "frac_useful": compulsory / avg_launch_s / 1e9 / HBM_PEAK_GBS,
             "achieved_definition": ("HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE) / "
                                     "launch duration by HIP events" if traffic else
                                     "compulsory 12 B per cell per launch (no PMC pass committed for this "
                                     "configuration) / launch duration by HIP events"),
             "traffic": traffic,
+            # the row of `traffic_source` the bytes can be recomputed from: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024
+            "traffic_row": pmc.get("kernel") if pmc else None,
             "traffic_source": pmc["source"] if pmc else ("stale: " + pmc_any["source"] + " was measured on other kernel "
                                                          "sources; compulsory bytes used" if pmc_any else None),
             "kernel_source_sha16": kernel_source_hash(),

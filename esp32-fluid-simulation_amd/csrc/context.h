@@ -77,7 +77,7 @@ class Group;
 // The automatic halo depth of a slab's solves is DECIDED BY TIMING REAL SOLVES (sor_executor.cpp choose_halo): a model with the
 // measured exchange as its input names up to three candidate depths, each of the first solves of a kind -- same iteration
 // count, fuse depth, tail and schedule -- runs on one of them between two events (every depth gives the same bits), and the
-// fastest is kept for that kind from then on.
+// fastest is kept for that kind from then on (another depth has to beat the legacy one by 1.5 %).
 struct HaloTuner {
     struct Kind {
         int iters, fuse, tail, in_time;
@@ -87,7 +87,7 @@ struct HaloTuner {
         Kind kind;
         int halo;
     };
-    static constexpr int kCandidates = 3, kSolvesEach = 3;   // (the first solve on a depth is not timed: new tilings, cold caches)
+    static constexpr int kCandidates = 3, kSolvesEach = 4;   // (the first solve on a depth is not timed: new tilings, cold caches)
     std::vector<Decided> decided;
     bool active = false;
     Kind kind{};

@@ -142,8 +142,8 @@ int effective_halo(const sfl_context *c, int fuse, int iters, bool in_time)
 // Halo depth of THIS solve (see HaloTuner).  Candidates: the legacy depth, the model's favourite, the deepest the slab can
 // carry.  Until the kind is decided, solve after solve runs on the candidates in turn between two events on the compute
 // stream; the elapsed time of a solve is read when the next one is issued (a host wait for a solve that was queued a whole
-// call ago: only during these first 9 solves of a kind).  RCCL ranks decide on the maximum over the ranks -- a collective at
-// the tenth solve, which every rank reaches in step (the ranks of a communicator issue the same calls).  An explicit
+// call ago: only during these first 12 solves of a kind).  RCCL ranks decide on the maximum over the ranks -- a collective at
+// the thirteenth solve, which every rank reaches in step (the ranks of a communicator issue the same calls).  An explicit
 // SFL_OPT_SOR_HALO switches all of this off.
 static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool *timed_solve)
 {
@@ -211,7 +211,7 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
     }
     int best = 0;
     for (int k = 1; k < t.ncand; ++k)
-        if (us[k] < us[best] && us[k] * 100 < us[0] * 99) best = k;   // (another depth has to beat the legacy one by 1 %)
+        if (us[k] < us[best] && us[k] * 1000 < us[0] * 985) best = k;   // (another depth has to beat the legacy one by 1.5 %: box noise)
     t.decided.push_back(HaloTuner::Decided{kind, t.cand[best]});
     t.active = false;
     return t.cand[best];

@@ -11,6 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 from bench import kernel_source_hash  # noqa: E402
 
 
@@ -22,8 +23,8 @@ def steady(v):
 def main():
     root, summary, dim_x, dim_y, fuse, rnd = sys.argv[1], sys.argv[2], *map(int, sys.argv[3:7])
     note = sys.argv[7] if len(sys.argv) > 7 else ""
-    want = f"Li{fuse}ELb"      # mangled Lane2<fuse, ...>; the continuing (not zero_in) instantiation is the dominant one
-    counters, dur = {}, []
+    from kernel_names import short   # the row of the summary the numbers can be read from
+    counters, dur, row = {}, [], None
     for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if "sor_fused_kernel" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
@@ -31,6 +32,7 @@ def main():
         for r in rows:
             if is_continuing(r["Kernel_Name"], fuse):
                 by.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                row = short(r["Kernel_Name"])
         for k, v in by.items():
             counters[k] = sum(steady(v)) / len(steady(v))
     for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True):
@@ -43,7 +45,9 @@ def main():
     read_b = counters["FETCH_SIZE"] * 1024 * 2       # gfx950: FETCH_SIZE reports half (MI355X_MICROARCH.md)
     write_b = counters["WRITE_SIZE"] * 1024
     entry = {"round": rnd, "grid": [dim_x, dim_y], "fuse": fuse, "n_gpus": 1,
-             "kernel": f"sor_fused_kernel<Lane2, NS={fuse}, dx1=true, zero_in=false>", "note": note,
+             "kernel": row or f"sor_fused_kernel<Lane2, NS={fuse}, dx1=true, zero_in=false>", "note": note,
+             "recompute": "traffic_bytes_per_launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 of this kernel's row in `source`; "
+                          "avg_launch_us_rocprof = its steady-state avg_us in the kernel trace section",
              "kernel_source_sha16": kernel_source_hash(),
              "fetch_size_kib_raw": counters["FETCH_SIZE"], "read_bytes_per_launch": int(read_b),
              "write_bytes_per_launch": int(write_b), "traffic_bytes_per_launch": int(read_b + write_b),

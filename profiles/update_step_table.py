@@ -11,6 +11,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from kernel_names import short  # noqa: E402  (the row of the summary the numbers can be read from)
 from bench import HBM_PEAK_GBS, STEP_KERNELS, step_kernel_source_hash  # noqa: E402
 
 
@@ -29,7 +31,7 @@ def which(name):
 def main():
     root, summary, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3])
     dim_x, dim_y = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (8192, 8192)
-    counters, dur = {}, {}
+    counters, dur, rows_named = {}, {}, {}
     for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
@@ -38,6 +40,7 @@ def main():
             k = which(r["Kernel_Name"])
             if k:
                 by.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+                rows_named[k] = short(r["Kernel_Name"])
         for (k, c), v in by.items():
             counters.setdefault(k, {})[c] = sum(steady(v)) / len(steady(v))
     for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True):
@@ -57,7 +60,7 @@ def main():
         read_b = c["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE reports half (MI355X_MICROARCH.md)
         write_b = c["WRITE_SIZE"] * 1024
         us = sum(d) / len(d) / 1e3
-        entry = {"round": rnd, "grid": [dim_x, dim_y], "kernel": k, "does": rec["does"],
+        entry = {"round": rnd, "grid": [dim_x, dim_y], "kernel": k, "summary_row": rows_named.get(k), "does": rec["does"],
                  "kernel_source_sha16": step_kernel_source_hash(),
                  "algorithmic_bytes_per_cell": rec["bytes_per_cell"], "algorithmic_bytes_per_launch": rec["bytes_per_cell"] * cells,
                  "read_bytes_per_launch": int(read_b), "write_bytes_per_launch": int(write_b),

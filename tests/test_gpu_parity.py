@@ -1327,6 +1327,30 @@ def test_emulated_rank_with_chained_launches(sfl, mode, rank):
         s.synchronize()
 
 
+@pytest.mark.parametrize("overlap,halo", [(1, 0), (1, 32), (0, 0)])
+def test_zero_iterations_on_slabs(sfl, overlap, halo):
+    """poisson_solve with iters == 0 still zero-fills p (poisson.cpp:117-119) -- on slabs too.  The early-exchange plan used to
+    index its empty tables at n - 1 for it (found by UBSan on the host side, tests/cpp/host_san_driver.cpp)."""
+    dim_x, dim_y, nranks = 256, 900, 3
+    _, _, d = random_fields(dim_x, dim_y, 4)
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        sfl.Solver.link_group(slabs)
+        slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
+        slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, 0)
+        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
+        for s in slabs:
+            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_PRESSURE, d[s.row_begin:s.row_end])
+        slabs[0].poisson_solve(1.0, 0, OMEGA)
+        slabs[0].synchronize()
+        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
+    finally:
+        for s in slabs:
+            s.close()
+    assert not got.any()
+
+
 @pytest.mark.parametrize("rank,dim_x,dim_y,iters,arrival", [
     (3, 640, 2048, 12, -1), (0, 640, 2048, 12, -1), (7, 1030, 4096, 25, -1), (3, 8192, 8192, 30, -1), (3, 640, 2048, 12, 0),
     (1, 2048, 1024, 20, 1)])
