@@ -264,6 +264,9 @@ def pmc_record(grid, fuse, world):
     return best, bool(best) and best.get("kernel_source_sha16") == kernel_source_hash()
 
 
+# untimed sim steps in front of the timed ones: the GPU's clocks, and -- on slabs -- the first 12 solves of a kind, which run on
+# candidate halo depths between events (csrc/sor_executor.cpp choose_halo; the 13th decides, collectively on RCCL ranks)
+SIM_PRIMING_STEPS = 16
 SCHEDULES = {0: "none", 1: "in line", 2: "one launch early, behind events", 3: "in time, counted on the device"}
 
 
@@ -738,7 +741,7 @@ def run_rank(args):
         # checked after the step for the dye -- no host round trip inside a step, never an SFL_ERR_HALO)
         dtf = np.float32(1 / 30.0)
         # the downloads above left the GPU idle: bring it back to its sustained clocks with untimed steps
-        for _ in range(1 if args.no_priming else 12):
+        for _ in range(1 if args.no_priming else SIM_PRIMING_STEPS):
             s.step(dtf, 1.0, iters, omega)
         sync_soft()
         rdzv.barrier()
@@ -783,7 +786,7 @@ def run_rank(args):
                 with sfl.Solver(size, dim_y, device=local_rank) as ref:
                     ref.upload(capi.FIELD_VELOCITY, synthetic_velocity(size, 0, dim_y))
                     ref.upload(capi.FIELD_COLOR, synthetic_color(size, 0, dim_y))
-                    for _ in range((1 if args.no_priming else 12) + args.sim_steps):
+                    for _ in range((1 if args.no_priming else SIM_PRIMING_STEPS) + args.sim_steps):
                         ref.step(dtf, 1.0, iters, omega)
                     ref.step_n(args.sim_steps, dtf, 1.0, iters, omega)
                     ref.synchronize()
@@ -798,7 +801,7 @@ def run_rank(args):
         if errs or any(x is None for x in same):
             step_parity = {"error": errs[0] if errs else "no checksums"}
         else:
-            step_parity = {"what": f"velocity, colour and pressure after {(1 if args.no_priming else 12) + 2 * args.sim_steps} sim steps: "
+            step_parity = {"what": f"velocity, colour and pressure after {(1 if args.no_priming else SIM_PRIMING_STEPS) + 2 * args.sim_steps} sim steps: "
                                    "every rank's rows against the same steps on one whole-domain context (rank 0's GPU), by checksums",
                            "bit_exact": all(same), "ranks_differing": [r for r, ok in enumerate(same) if not ok]}
 

@@ -94,7 +94,7 @@ struct HaloTuner {
     int cand[kCandidates] = {0, 0, 0}, ncand = 0;
     int solve_no = 0, pending = -1;      // exploratory solves issued so far; candidate of the solve between the two events
     bool pending_timed = false;
-    float total_ms[kCandidates] = {0, 0, 0};
+    float total_ms[kCandidates] = {0, 0, 0};   // the fastest timed solve of each candidate so far
     int timed[kCandidates] = {0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~HaloTuner()

@@ -180,7 +180,8 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
         float ms = 0.0f;
         if (hipEventSynchronize(t.ev1) == hipSuccess && hipEventElapsedTime(&ms, t.ev0, t.ev1) == hipSuccess && t.pending_timed &&
             ms > 0.0f && ms < 1e5f) {   // (a solve that failed half way left its events in no usable order)
-            t.total_ms[t.pending] += ms;
+            // the FASTEST of a depth's timed solves stands for it: a stall of the host or a clock step hits one solve, not three
+            t.total_ms[t.pending] = t.timed[t.pending] ? std::min(t.total_ms[t.pending], ms) : ms;
             ++t.timed[t.pending];
         }
         t.pending = -1;
@@ -195,7 +196,7 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
     }
     // decide: microseconds per solve of each candidate, the maximum over the ranks where they are separate processes
     int us[HaloTuner::kCandidates] = {0, 0, 0};
-    for (int k = 0; k < t.ncand; ++k) us[k] = t.timed[k] ? (int)(t.total_ms[k] * 1e3f / t.timed[k] + 0.5f) : (k == 0 ? 0 : 1 << 30);
+    for (int k = 0; k < t.ncand; ++k) us[k] = t.timed[k] ? (int)(t.total_ms[k] * 1e3f + 0.5f) : (k == 0 ? 0 : 1 << 30);
     if (t.ncand > 1 && reduces_on_device(ctx)) {
         int *dev = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&dev), sizeof us) == hipSuccess) {
@@ -212,6 +213,11 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
     int best = 0;
     for (int k = 1; k < t.ncand; ++k)
         if (us[k] < us[best] && us[k] * 1000 < us[0] * 985) best = k;   // (another depth has to beat the legacy one by 1.5 %: box noise)
+    if (getenv("SFL_TUNER_LOG"))   // (what the choice was made from, for whoever wants to see it)
+        fprintf(stderr, "sfl halo tuner: slab %d/%d iters %d fuse %d tail %d %s: exchange %d us + %d ns/row; candidates %d / %d / %d rows: "
+                "%d / %d / %d us per solve -> %d rows\n", ctx->rank, ctx->nranks, iters, fuse, ctx->solve_tail, in_time ? "in time" : "by events",
+                ctx->exchange_latency_us, ctx->exchange_ns_per_row, t.cand[0], t.ncand > 1 ? t.cand[1] : 0, t.ncand > 2 ? t.cand[2] : 0,
+                us[0], t.ncand > 1 ? us[1] : 0, t.ncand > 2 ? us[2] : 0, t.cand[best]);
     t.decided.push_back(HaloTuner::Decided{kind, t.cand[best]});
     t.active = false;
     return t.cand[best];
