@@ -187,9 +187,13 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
         t.pending = -1;
     }
     if (t.ncand > 1 && t.solve_no < t.ncand * HaloTuner::kSolvesEach) {
-        const int k = t.solve_no / HaloTuner::kSolvesEach;
+        // the candidates take turns, round after round, every second round in reverse order: the first solves after a pause run
+        // at clocks that are still climbing (2.7 -> 1.9 ms over the first 15 solves of 8192^2), and a candidate measured as a
+        // block would be judged by WHEN it ran (C5 with self-copies: the deepest halo, timed last, was chosen 3.5 % too slow)
+        const int round = t.solve_no / t.ncand, pos = t.solve_no % t.ncand;
+        const int k = (round & 1) ? t.ncand - 1 - pos : pos;
         t.pending = k;
-        t.pending_timed = t.solve_no % HaloTuner::kSolvesEach != 0;
+        t.pending_timed = round != 0;   // the first round is every depth's warm-up (new tilings, cold caches)
         ++t.solve_no;
         *timed_solve = true;
         return t.cand[k];

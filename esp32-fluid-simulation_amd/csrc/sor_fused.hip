@@ -159,7 +159,7 @@ __device__ __forceinline__ int relax_tile(float *p_out, const float *p_in, const
 template <class B, int NS, bool DX1, bool ZERO_IN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd(NS))))
 sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::Tiling t1,
-                 sor::Tiling t2, SorParams prm, HaloWait hw)
+                 sor::Tiling t2, SorParams prm, HaloWait hw, int rot_c, int rot_e, int free_blocks)
 {
     __shared__ __attribute__((aligned(16))) float ring_mem[kWavesPerBlock][B::kRingFloats];
 #if defined(SFL_PROBE_COOP) && SFL_PROBE_COOP == 3
@@ -178,10 +178,8 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // horizontally / vertically adjacent tiles -- which re-read each other's halo columns and
     // rows -- hit in the same L2.  Speed only: any placement computes the same result.
     // The blocks that hold tiles which wait for a halo message inside the launch keep the dispatcher's own rotation over the
-    // XCDs and come LAST (sor::tile_of_position has the reason); the contiguous ranges are dealt over the blocks in front.
-    const int nblocks = gridDim.x;
+    // XCDs and come LAST (sor::tile_rect has the reason); the contiguous ranges are dealt over the blocks in front.
     int block = blockIdx.x;
-    const int free_blocks = t2.n_tiles ? nblocks : (sor::free_tiles(t1) / kWavesPerBlock);
     if (block < free_blocks) {
         const int per = free_blocks >> 3, rem = free_blocks & 7;
         const int xcd = block & 7, idx = block >> 3;
@@ -191,7 +189,6 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     // the tiles of the second tiling follow those of the first
     int tile = block * kWavesPerBlock + wave;
     if (tile >= t1.n_tiles + t2.n_tiles) return;
-    if (tile < t1.n_tiles) tile = sor::tile_of_position(t1, tile);
 #ifdef SFL_SOR_TRACE
     WaveTrace trace;
     trace.begin();
@@ -201,7 +198,7 @@ sor_fused_kernel(float *p_out, const float *p_in, const float *d, Slab g, sor::T
     const bool second = tile >= t1.n_tiles;  // wave-uniform
     const sor::Tiling t = second ? t2 : t1;
     if (second) tile -= t1.n_tiles;
-    const sor::TileRect rect = sor::tile_rect(t, tile);
+    const sor::TileRect rect = sor::tile_rect(t, tile, second ? 0 : rot_c, second ? 0 : rot_e);
     const int r0 = rect.r0, r1 = rect.r1;
 
     // Halo arrival inside the launch (kernels.h HaloWait): a tile that reads a row a halo message writes -- in either
@@ -358,24 +355,26 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     const int blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     HaloWait hw = wait ? *wait : HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0};
     if (hw.timeout_us <= 0) hw.timeout_us = kHaloWaitDefaultTimeoutUs;
+    // dispatch order (sor::tile_rect): nothing special unless tiles of this launch will wait inside it -- then the chunks that do
+    // not wait first (the same test as the kernel's, on the chunks of an inner strip and of a boundary strip), and only their
+    // blocks in the XCD-contiguous deal
+    int rot_c = 0, rot_e = 0, free_blocks = blocks;
     if (hw.flag != nullptr && t2.n_tiles == 0) {
-        // the tiles that will wait inside the launch go last (sor::tile_of_position): the same test as the kernel's, on the
-        // chunks of an inner strip and of a boundary strip (chunks are numbered bottom-up: the free ones are one range)
         const int line_rows = (g.dim_x & 63) ? 1 + 63 / g.dim_x : 0;
         const int reach = NS + sor::ring_rows(NS) + line_rows;
-        auto free_range = [&](int strip, int n_chunks, int *c0, int *c1) {
-            *c0 = *c1 = 0;
-            bool any = false;
+        auto free_range = [&](int strip, int n_chunks, int *c0, int *count) {
+            *c0 = *count = 0;
             for (int c = 0; c < n_chunks; ++c) {
                 const sor::TileRect r = sor::tile_rect(t1, sor::tile_index(t1, strip, c));
                 if (r.r0 - reach < hw.own_lo || r.r1 + reach > hw.own_hi) continue;
-                if (!any) *c0 = c;
-                any = true;
-                *c1 = c + 1;
+                if (*count == 0) *c0 = c;
+                ++*count;
             }
         };
-        if (t1.n_inner > 0) free_range(1, t1.n_chunks, &t1.free_c0, &t1.free_c1);
-        free_range(0, t1.n_chunks_edge, &t1.free_e0, &t1.free_e1);
+        int fc = 0, fe = 0;
+        if (t1.n_inner > 0) free_range(1, t1.n_chunks, &rot_c, &fc);
+        free_range(0, t1.n_chunks_edge, &rot_e, &fe);
+        free_blocks = fc * t1.n_inner / kWavesPerBlock;
     }
     if (senders) {   // the same test as the kernel's, on the same tilings
         int n = 0;
@@ -387,7 +386,7 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
                 }
         *senders = n;
     }
-    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm, hw);
+    sor_fused_kernel<B, NS, DX1, ZERO_IN><<<blocks, kThreads, 0, s>>>(p_out, p_in, d, g, t1, t2, prm, hw, rot_c, rot_e, free_blocks);
     return hipGetLastError();
 }
 

@@ -347,10 +347,6 @@ struct Tiling {
                           // (2 = this wave at the top priority throughout: set per tile by the kernel for sender tiles)
     int flip;             // every second chunk of an inner strip is streamed top-down (see tile_rect):
                           // 1 = the odd chunks, 2 = the even ones, 0 = none
-    // DISPATCH ORDER (tile_of_position): the chunks [free_c0, free_c1) of the inner strips and [free_e0, free_e1) of the
-    // boundary strips come first, the other chunks -- the launcher puts there the tiles that will WAIT for a halo message
-    // inside the launch -- last.  Defaults (make_tiling): every chunk is free, the order is the tile index.
-    int free_c0, free_c1, free_e0, free_e1;
 };
 
 struct TileRect {
@@ -425,9 +421,6 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
     t.n_chunks = (t.rows_first > 0) + (mid + rows_per_chunk - 1) / rows_per_chunk + (t.rows_last > 0);
     t.n_chunks_edge = (rows + t.rows_edge - 1) / t.rows_edge;
     t.n_tiles = t.n_inner * t.n_chunks + (t.n_strips - t.n_inner) * t.n_chunks_edge;
-    t.free_c0 = t.free_e0 = 0;
-    t.free_c1 = t.n_chunks;
-    t.free_e1 = t.n_chunks_edge;
     return t;
 }
 
@@ -439,15 +432,30 @@ SFL_HD Tiling make_tiling(int ns, int tile_cols, int col_align, int dim_x, int g
 // at the END of its life and its upper neighbour at the BEGINNING of its own -- a tile's life apart,
 // long evicted from L2.  With alternating directions both sharers reach a shared band at the same
 // moment (both at the start, or both at the end): the second read hits the XCD's L2.
-SFL_HD TileRect tile_rect(const Tiling &t, int tile)
+//
+// DISPATCH ORDER (rot_c, rot_e): a launch whose cut-adjacent tiles wait INSIDE the kernel for a halo message (kernels.h HaloWait)
+// must not hand those tiles out first.  The dispatcher deals workgroups to the XCDs in strict rotation and an XCD's share of the
+// tiles in index order; with the bottom rows first the first XCD fills up with waiting tiles, none of which ever retires -- and
+// the workgroups of the kernel that DELIVERS the message (RCCL's, dealt to the XCDs in the same rotation) find no room there: the
+// launch waits for the message and the message for the launch, until the wait gives up (seen with sfl_comm_emulate_rccl on
+// 16384 x 2048 slabs at a 160-row halo, profiles/r05_emulate_rccl.txt).  Chunks are numbered bottom-up and a tile waits when its
+// rows come within reach of a cut, so the tiles that do NOT wait are one range of chunks [c0, c0 + fc) per kind of strip: the
+// index `tile` is taken as a POSITION whose chunk number is rotated by rot = c0 -- the free chunks first, then the waiting ones
+// above them, then (wrapped round) the waiting ones below.  A rotation, not a general permutation, on purpose: one add and one
+// compare; a position -> tile map with quotients cost the NS = 16 kernel 1400 extra v_readlane / v_writelane in its streaming
+// loop (SGPR pressure at the top of the kernel decides what is spilled for the whole loop) and 5 % of its time.
+SFL_HD TileRect tile_rect(const Tiling &t, int tile, int rot_c = 0, int rot_e = 0)
 {
     TileRect r;
     r.flip = 0;
     const int inner_tiles = t.n_inner * t.n_chunks;
     if (tile < inner_tiles) {
-        const int chunk = tile / t.n_inner;
+        int chunk = tile / t.n_inner;
+        const int strip_in_chunk = tile - chunk * t.n_inner;
+        chunk += rot_c;
+        if (chunk >= t.n_chunks) chunk -= t.n_chunks;
         r.flip = t.flip && ((chunk & 1) == (t.flip & 1));  // flip = 1: the odd chunks, 2: the even ones
-        r.strip = 1 + (tile - chunk * t.n_inner);
+        r.strip = 1 + strip_in_chunk;
         const int has_first = t.rows_first > 0;
         if (has_first && chunk == 0) {
             r.r0 = t.g_begin;
@@ -463,48 +471,13 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile)
     } else {
         const int u = tile - inner_tiles;
         const int e = u / t.n_chunks_edge;
-        const int chunk = u - e * t.n_chunks_edge;
+        int chunk = u - e * t.n_chunks_edge + rot_e;
+        if (chunk >= t.n_chunks_edge) chunk -= t.n_chunks_edge;
         r.strip = e == 0 ? 0 : t.n_inner + e;
         r.r0 = t.g_begin + chunk * t.rows_edge;
         r.r1 = r.r0 + t.rows_edge < t.g_end ? r.r0 + t.rows_edge : t.g_end;
     }
     return r;
-}
-
-// ---- dispatch order ---------------------------------------------------------------------------------------------------
-// A launch whose cut-adjacent tiles wait INSIDE the kernel for a halo message (kernels.h HaloWait) must not hand those
-// tiles out first: the dispatcher deals workgroups to the XCDs in strict rotation and an XCD's tiles in index order, so
-// with the bottom rows first the first XCD fills up with waiting tiles, none of which ever retires -- and the workgroups of
-// the kernel that DELIVERS the message (RCCL's, dealt to the XCDs in the same rotation) find no room there: the launch
-// waits for the message and the message for the launch, until the wait gives up (seen with sfl_comm_emulate_rccl on
-// 16384 x 2048 slabs at a 160-row halo, profiles/r05_emulate_rccl.txt).  So: the tiles that do not wait first, in the
-// XCD-contiguous order as before; the waiting tiles behind them, dealt round-robin over all XCDs, each of which then
-// holds only an eighth of them and turns its other slots over.  Chunks are numbered bottom-up and a tile waits when its
-// rows come within reach of a cut, so the free tiles are ONE range of chunks per kind of strip.
-SFL_HD int free_tiles(const Tiling &t)
-{
-    const int fc = t.free_c1 > t.free_c0 ? t.free_c1 - t.free_c0 : 0, fe = t.free_e1 > t.free_e0 ? t.free_e1 - t.free_e0 : 0;
-    return fc * t.n_inner + fe * (t.n_strips - t.n_inner);
-}
-
-// position in the dispatch order -> tile index; a bijection of [0, n_tiles) whatever the two ranges are
-SFL_HD int tile_of_position(const Tiling &t, int q)
-{
-    const int fc = t.free_c1 > t.free_c0 ? t.free_c1 - t.free_c0 : 0, fe = t.free_e1 > t.free_e0 ? t.free_e1 - t.free_e0 : 0;
-    const int c0 = fc ? t.free_c0 : 0, e0 = fe ? t.free_e0 : 0;   // (an empty range: everything of that kind waits)
-    const int inner_tiles = t.n_inner * t.n_chunks, n_edge = t.n_strips - t.n_inner;
-    if (q < fc * t.n_inner) return c0 * t.n_inner + q;                       // free chunks of the inner strips (chunk-major)
-    q -= fc * t.n_inner;
-    if (q < fe * n_edge) return inner_tiles + (q / fe) * t.n_chunks_edge + e0 + q % fe;   // free chunks of the boundary strips
-    q -= fe * n_edge;
-    if (q < c0 * t.n_inner) return q;                                        // waiting: inner chunks below the free range
-    q -= c0 * t.n_inner;
-    const int above = (t.n_chunks - c0 - fc) * t.n_inner;
-    if (q < above) return (c0 + fc) * t.n_inner + q;                         // ... above it
-    q -= above;
-    const int per = t.n_chunks_edge - fe;                                    // ... and of each boundary strip
-    const int e = q / per, r = q - e * per;
-    return inner_tiles + e * t.n_chunks_edge + (r < e0 ? r : r + fe);
 }
 
 // ---- which tiles of ANOTHER tiling of the same columns does a row range touch? (chained supersteps: sor_fused.hip) ----

@@ -324,7 +324,7 @@ int reduce_max_then_copy(sfl_context *ctx, int *dev_words, int n, int *host_word
     return SFL_OK;
 }
 
-// One wave on the compute stream waits (at most 50 ms) for a word that a kernel on the exchange stream raises.  Streams
+// One wave on the compute stream waits (at most 200 ms) for a word that a kernel on the exchange stream raises.  Streams
 // that share a hardware queue run in submission order: the raise then sits behind the wait, which gives up.  (The
 // runtime folds its streams onto GPU_MAX_HW_QUEUES queues, 4 by default, in turn: an application with many streams
 // of its own can put a context's two streams on one.)
@@ -337,9 +337,15 @@ int streams_run_concurrently(sfl_context *ctx, bool *yes)
         int *w = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w), 2 * sizeof(int)));
         int h[2] = {0, 1};
+        // (both streams have run a kernel before the clock starts: the first use of a stream creates its hardware queue, which
+        // can take longer than any sensible limit of the wait below -- the first group of a process was found "not concurrent")
         hipError_t e = hipMemsetAsync(w, 0, 2 * sizeof(int), o.compute);
+        if (e == hipSuccess) e = launch_signal_arrival(o.compute, w, 0);
+        if (e == hipSuccess) e = hipStreamSynchronize(o.compute);
+        if (e == hipSuccess) e = launch_signal_arrival(o.xstream, w, 0);
+        if (e == hipSuccess) e = hipStreamSynchronize(o.xstream);
         if (e == hipSuccess) e = hipEventRecord(o.ready, o.compute);
-        if (e == hipSuccess) e = launch_wait_count(o.compute, w, 1, w + 1, 50000);
+        if (e == hipSuccess) e = launch_wait_count(o.compute, w, 1, w + 1, 200000);
         if (e == hipSuccess) e = hipStreamWaitEvent(o.xstream, o.ready, 0);
         if (e == hipSuccess) e = launch_signal_arrival(o.xstream, w, 1);
         if (e == hipSuccess) e = hipStreamSynchronize(o.xstream);

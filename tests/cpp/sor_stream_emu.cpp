@@ -361,33 +361,30 @@ emu_tiling_deps(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int
     return pairs;
 }
 
-// Dispatch order (sor::tile_of_position): for free chunk ranges [c0, c1) of the inner strips and [e0, e1) of the boundary
-// strips -- any ranges, also empty or out of bounds after clipping -- the map position -> tile must be a bijection of
-// [0, n_tiles), with exactly free_tiles() free tiles in front.  Returns n_tiles, or -1 at the first violation.
+// Dispatch order (sor::tile_rect's rotation): for any rotation of the chunk numbers of the inner strips (rot_c) and of the
+// boundary strips (rot_e) the map position -> (strip, output rows) must visit every tile of the tiling exactly once, and the
+// first fc x n_inner positions must be the chunks [rot_c, rot_c + fc) of the inner strips.  Returns n_tiles, or -1.
 extern "C" __attribute__((visibility("default"))) int
 emu_tile_order(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int g_begin, int g_end, int rows_per_chunk,
                int balance, int c0, int c1, int e0, int e1)
 {
     using namespace sfl::sor;
-    Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk, balance);
-    for (int q = 0; q < t.n_tiles; ++q)
-        if (tile_of_position(t, q) != q) return -1;   // the default order is the tile index
+    const Tiling t = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, g_begin, g_end, rows_per_chunk, balance);
     auto clip = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-    t.free_c0 = clip(c0, t.n_chunks);
-    t.free_c1 = clip(c1, t.n_chunks);
-    t.free_e0 = clip(e0, t.n_chunks_edge);
-    t.free_e1 = clip(e1, t.n_chunks_edge);
+    const int rot_c = t.n_chunks ? clip(c0, t.n_chunks - 1) : 0, rot_e = t.n_chunks_edge ? clip(e0, t.n_chunks_edge - 1) : 0;
+    const int fc = clip(c1, t.n_chunks - rot_c);   // free chunks of the inner strips: [rot_c, rot_c + fc)
+    (void)e1;
     std::vector<char> seen(t.n_tiles, 0);
-    const int free = free_tiles(t);
     for (int q = 0; q < t.n_tiles; ++q) {
-        const int k = tile_of_position(t, q);
+        const TileRect r = tile_rect(t, q, rot_c, rot_e);
+        if (r.strip < 0 || r.strip >= t.n_strips || r.r0 >= r.r1 || r.r0 < t.g_begin || r.r1 > t.g_end) return -1;
+        const int chunk = chunk_of_row(t, r.strip, r.r0);
+        const int k = tile_index(t, r.strip, chunk);
+        const TileRect plain = tile_rect(t, k);
+        if (plain.strip != r.strip || plain.r0 != r.r0 || plain.r1 != r.r1) return -1;   // a tile of the tiling, as the tiling cuts it
         if (k < 0 || k >= t.n_tiles || seen[k]) return -1;
         seen[k] = 1;
-        const TileRect r = tile_rect(t, k);
-        const bool inner = strip_is_inner(t, r.strip);
-        const int chunk = chunk_of_row(t, r.strip, r.r0);
-        const bool is_free = inner ? (chunk >= t.free_c0 && chunk < t.free_c1) : (chunk >= t.free_e0 && chunk < t.free_e1);
-        if (is_free != (q < free)) return -1;   // the free tiles, and only they, come first
+        if (q < fc * t.n_inner && !(strip_is_inner(t, r.strip) && chunk >= rot_c && chunk < rot_c + fc)) return -1;
     }
     return t.n_tiles;
 }
