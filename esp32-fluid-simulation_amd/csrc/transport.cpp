@@ -617,6 +617,14 @@ int sfl_group_link(sfl_context **ctxs, int n)
     auto g = std::make_shared<Group>();
     g->members.assign(ctxs, ctxs + n);
     HIP_TRY(hipSetDevice(ctxs[0]->device));
+    // The members' own streams go FIRST: the runtime folds its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    // default), and with the members' streams still alive the group's compute and exchange stream of the first group of a
+    // process landed on ONE queue (found by streams_run_concurrently: that group fell back to exchanges behind events).
+    for (int r = 0; r < n; ++r) {
+        (void)hipStreamSynchronize(ctxs[r]->stream);
+        (void)hipStreamDestroy(ctxs[r]->stream);
+        ctxs[r]->stream = nullptr;
+    }
     // the group's streams, one behind the other: the runtime deals streams to its hardware queues in turn
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&g->xstream, hipStreamNonBlocking));
@@ -643,8 +651,6 @@ int sfl_group_link(sfl_context **ctxs, int n)
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
         c->stream = g->stream;
         c->owns_stream = false;
         c->transport = g;

@@ -1160,7 +1160,7 @@ def test_chained_launch_across_halo_exchanges(sfl, oracle, nranks, dim_x, dim_y,
     try:
         sfl.Solver.link_group(slabs)
         slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
-        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
+        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo or 64)   # (0 would be a timed choice: this test wants its exchanges)
         slabs[0].set_option(sfl.capi.OPT_SOR_CHAIN, 1)
         assert slabs[-1].get_option(sfl.capi.OPT_SOR_CHAIN) == 1
         for s in slabs:
