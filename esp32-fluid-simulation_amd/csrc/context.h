@@ -87,20 +87,22 @@ struct HaloTuner {
         Kind kind;
         int halo;
     };
-    static constexpr int kCandidates = 3, kSolvesEach = 4;   // (the first solve on a depth is not timed: new tilings, cold caches)
+    static constexpr int kCandidates = 3, kSolvesEach = 4;   // (the first round is not timed: new tilings, cold caches)
+    static constexpr int kExplore = kCandidates * kSolvesEach;
     std::vector<Decided> decided;
     bool active = false;
     Kind kind{};
     int cand[kCandidates] = {0, 0, 0}, ncand = 0;
-    int solve_no = 0, pending = -1;      // exploratory solves issued so far; candidate of the solve between the two events
-    bool pending_timed = false;
-    float total_ms[kCandidates] = {0, 0, 0};   // the fastest timed solve of each candidate so far
-    int timed[kCandidates] = {0, 0, 0};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int solve_no = 0;                    // exploratory solves issued so far
+    int which[kExplore] = {0};           // the candidate exploratory solve n ran on
+    // a pair of events around every exploratory solve, read TOGETHER when the kind is decided: a host wait between two solves
+    // would time them in another regime than the one they run in afterwards (the GPU waiting for the host to queue launches
+    // favours the plan with fewer launches: the deepest halo was chosen 4 % too slow)
+    hipEvent_t ev[2 * kExplore] = {nullptr};
     ~HaloTuner()
     {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 

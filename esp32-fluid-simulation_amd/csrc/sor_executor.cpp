@@ -140,26 +140,22 @@ int effective_halo(const sfl_context *c, int fuse, int iters, bool in_time)
 }
 
 // Halo depth of THIS solve (see HaloTuner).  Candidates: the legacy depth, the model's favourite, the deepest the slab can
-// carry.  Until the kind is decided, solve after solve runs on the candidates in turn between two events on the compute
-// stream; the elapsed time of a solve is read when the next one is issued (a host wait for a solve that was queued a whole
-// call ago: only during these first 12 solves of a kind).  RCCL ranks decide on the maximum over the ranks -- a collective at
-// the thirteenth solve, which every rank reaches in step (the ranks of a communicator issue the same calls).  An explicit
-// SFL_OPT_SOR_HALO switches all of this off.
-static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool *timed_solve)
+// carry.  Until the kind is decided, solve after solve runs on the candidates in turn, each between its own pair of events on
+// the compute stream; nothing is read back meanwhile (the solves are queued as they are in steady state); the thirteenth solve
+// of the kind waits for the twelfth, reads the pairs and decides.  RCCL ranks decide on the maximum over the ranks -- a
+// collective at that solve, which every rank reaches in step (the ranks of a communicator issue the same calls).  An
+// explicit SFL_OPT_SOR_HALO switches all of this off.
+static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, int *timed_solve)
 {
-    *timed_solve = false;
+    *timed_solve = -1;
     HaloTuner &t = ctx->group ? ctx->group->halo_tuner : ctx->halo_tuner;
     if (ctx->opt_sor_halo || !ctx->transport || ctx->nranks < 2 || iters < 1 || ctx->exchange_latency_us < 0) {
         t.active = false;
-        t.pending = -1;
         return effective_halo(ctx, fuse, iters, in_time);
     }
     const HaloTuner::Kind kind{iters, fuse, ctx->solve_tail, in_time ? 1 : 0};
     for (const HaloTuner::Decided &d : t.decided)
-        if (d.kind == kind) {
-            t.pending = -1;
-            return d.halo;
-        }
+        if (d.kind == kind) return d.halo;
     if (!t.active || !(t.kind == kind)) {   // a new kind of solve: name the candidates
         t.active = true;
         t.kind = kind;
@@ -170,21 +166,6 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
             if (!seen) t.cand[t.ncand++] = h;
         }
         t.solve_no = 0;
-        t.pending = -1;
-        for (int k = 0; k < HaloTuner::kCandidates; ++k) {
-            t.total_ms[k] = 0.0f;
-            t.timed[k] = 0;
-        }
-    }
-    if (t.pending >= 0) {   // the previous exploratory solve: how long did it take?
-        float ms = 0.0f;
-        if (hipEventSynchronize(t.ev1) == hipSuccess && hipEventElapsedTime(&ms, t.ev0, t.ev1) == hipSuccess && t.pending_timed &&
-            ms > 0.0f && ms < 1e5f) {   // (a solve that failed half way left its events in no usable order)
-            // the FASTEST of a depth's timed solves stands for it: a stall of the host or a clock step hits one solve, not three
-            t.total_ms[t.pending] = t.timed[t.pending] ? std::min(t.total_ms[t.pending], ms) : ms;
-            ++t.timed[t.pending];
-        }
-        t.pending = -1;
     }
     if (t.ncand > 1 && t.solve_no < t.ncand * HaloTuner::kSolvesEach) {
         // the candidates take turns, round after round, every second round in reverse order: the first solves after a pause run
@@ -192,15 +173,25 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
         // block would be judged by WHEN it ran (C5 with self-copies: the deepest halo, timed last, was chosen 3.5 % too slow)
         const int round = t.solve_no / t.ncand, pos = t.solve_no % t.ncand;
         const int k = (round & 1) ? t.ncand - 1 - pos : pos;
-        t.pending = k;
-        t.pending_timed = round != 0;   // the first round is every depth's warm-up (new tilings, cold caches)
-        ++t.solve_no;
-        *timed_solve = true;
+        t.which[t.solve_no] = k;
+        *timed_solve = t.solve_no++;
         return t.cand[k];
     }
-    // decide: microseconds per solve of each candidate, the maximum over the ranks where they are separate processes
+    // decide: the FASTEST timed solve of each candidate (a stall of the host or a clock step hits one solve, not three; the
+    // first round is every depth's warm-up), the maximum over the ranks where they are separate processes
     int us[HaloTuner::kCandidates] = {0, 0, 0};
-    for (int k = 0; k < t.ncand; ++k) us[k] = t.timed[k] ? (int)(t.total_ms[k] * 1e3f + 0.5f) : (k == 0 ? 0 : 1 << 30);
+    for (int k = 1; k < HaloTuner::kCandidates; ++k) us[k] = 1 << 30;
+    if (t.ncand > 1) {
+        us[0] = 1 << 30;
+        const int last = t.solve_no - 1;
+        const bool done = t.ev[2 * last + 1] && hipEventSynchronize(t.ev[2 * last + 1]) == hipSuccess;
+        for (int n = t.ncand; done && n <= last; ++n) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, t.ev[2 * n], t.ev[2 * n + 1]) == hipSuccess && ms > 0.0f && ms < 1e5f)
+                us[t.which[n]] = std::min(us[t.which[n]], (int)(ms * 1e3f + 0.5f));
+        }
+        if (us[0] == 1 << 30) us[0] = 0;   // (nothing usable: the legacy depth)
+    }
     if (t.ncand > 1 && reduces_on_device(ctx)) {
         int *dev = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&dev), sizeof us) == hipSuccess) {
@@ -216,7 +207,7 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, bool
     }
     int best = 0;
     for (int k = 1; k < t.ncand; ++k)
-        if (us[k] < us[best] && us[k] * 1000 < us[0] * 985) best = k;   // (another depth has to beat the legacy one by 1.5 %: box noise)
+        if (us[k] < us[best] && (long)us[k] * 1000 < (long)us[0] * 985) best = k;   // (another depth has to beat the legacy one by 1.5 %: box noise)
     if (getenv("SFL_TUNER_LOG"))   // (what the choice was made from, for whoever wants to see it)
         fprintf(stderr, "sfl halo tuner: slab %d/%d iters %d fuse %d tail %d %s: exchange %d us + %d ns/row; candidates %d / %d / %d rows: "
                 "%d / %d / %d us per solve -> %d rows\n", ctx->rank, ctx->nranks, iters, fuse, ctx->solve_tail, in_time ? "in time" : "by events",
@@ -657,14 +648,14 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
     SFL_TRY(resolve_schedule(ctx));
     const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
     const bool in_time = in_time_exchanges(ctx);
-    bool timed_solve = false;
+    int timed_solve = -1;   // >= 0: an exploratory solve of the halo tuner, between its pair of events
     const int halo = kernel == 2 && !small_grid(ctx) ? choose_halo(ctx, fuse, iters, in_time, &timed_solve) : effective_halo(ctx, fuse, iters, in_time);
     HaloTuner &tuner = ctx->group ? ctx->group->halo_tuner : ctx->halo_tuner;
-    if (timed_solve) {
+    if (timed_solve >= 0) {
         SFL_TRY(use_device(ctx));
-        if (!tuner.ev0) HIP_TRY(hipEventCreate(&tuner.ev0));
-        if (!tuner.ev1) HIP_TRY(hipEventCreate(&tuner.ev1));
-        HIP_TRY(hipEventRecord(tuner.ev0, ctx->stream));
+        for (int k = 0; k < 2; ++k)
+            if (!tuner.ev[2 * timed_solve + k]) HIP_TRY(hipEventCreate(&tuner.ev[2 * timed_solve + k]));
+        HIP_TRY(hipEventRecord(tuner.ev[2 * timed_solve], ctx->stream));
     }
     std::vector<std::vector<sfl_plan_step>> progs;
     for (sfl_context *c : peers) {
@@ -717,9 +708,9 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         if (c->rank < c->nranks - 1) tail = std::min(tail, last.g_end - c->g1);
     }
     for (sfl_context *c : peers) c->p_ghost_valid = tail > 0 ? tail : 0;
-    if (timed_solve) {
+    if (timed_solve >= 0) {
         SFL_TRY(use_device(ctx));
-        HIP_TRY(hipEventRecord(tuner.ev1, ctx->stream));
+        HIP_TRY(hipEventRecord(tuner.ev[2 * timed_solve + 1], ctx->stream));
     }
     return SFL_OK;
 }
