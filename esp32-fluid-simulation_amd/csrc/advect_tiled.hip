@@ -118,7 +118,7 @@ advect_vec2f_tiled_kernel(float2 *__restrict__ next_p, const float2 *p, const fl
     __shared__ float2 tile[kSY * kSX];
     int tx, ty;
     if (!tile_of_block(tg, tx, ty)) return;
-    // a launch covers up to two row ranges (the two bands of a slab next to its cuts in one launch: sfl_api.cpp
+    // a launch covers up to two row ranges (the two bands of a slab next to its cuts in one launch: operators.cpp
     // advect_velocity_planned): the rows of tiles from ny1 on belong to [g2_begin, g2_end)
     if (ty >= ny1) {
         g_begin = g2_begin - ny1 * kTY;
@@ -388,7 +388,7 @@ gradient_tiled_kernel(float2 *v, const float *__restrict__ p, Slab g, TileGrid t
 // REACH (slabs, FUSE_GRAD): the back-traces of this kernel are those of the NEXT step's velocity advection -- same projected
 // velocity, same dt, same rows -- so the kernel also leaves what backtrace_reach_kernel would measure afterwards (three launches,
 // 31 us on a 1024-row slab, on the critical path between two steps): `halo_flag` then points at word [2] of a reach report
-// (sfl_api.cpp kReachWords) and words [0], [1], [3] .. [7] are raised with atomicMax, one per wave and word.
+// (context.h kReachWords) and words [0], [1], [3] .. [7] are raised with atomicMax, one per wave and word.
 template <bool NO_SLIP, bool FUSE_GRAD, int THREADS, bool REACH = false>
 __global__ void __launch_bounds__(THREADS)
 advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, float2 *vel, Slab g, Slab gs,
@@ -472,7 +472,7 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
                 need[5] = max(need[5], top - (g_end - 1));
             }
             // [3]: how many rows from its own row a cell's sources lie at most -- rows further than that from both ends of the
-            // slab never read beyond it (sfl_api.cpp advect_interior_early)
+            // slab never read beyond it (slab_step.cpp advect_interior_early)
             need[6] = max(need[6], max(gj - s.cj, top - gj));
         }
         if (!rows_available(s, valid_begin, valid_end)) {

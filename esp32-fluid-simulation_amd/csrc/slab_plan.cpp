@@ -67,7 +67,7 @@ std::vector<sfl_plan_step> plan_poisson(int dim_y, int nranks, int rank, int ite
 
     // kernel 3 = kernel 2's launches with IN-TIME exchanges at every halo depth: the halo of a superstep is sent after the
     // launch that produces it (the executor lets it leave as soon as that launch's cut-adjacent tiles are done and lets
-    // only the next launch's cut-adjacent tiles wait for it: sfl_api.cpp run_poisson_in_time)
+    // only the next launch's cut-adjacent tiles wait for it: sor_executor.cpp run_poisson_in_time)
     const bool in_time = kernel == 3;
     if (tail < 0 || !multi || (!in_time && halo < 2 * fuse + tail) || (in_time && halo < fuse + tail)) tail = 0;
     if (multi && halo >= 2 * fuse && !in_time) {

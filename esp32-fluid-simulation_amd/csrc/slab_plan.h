@@ -1,7 +1,7 @@
 // slab_plan.h -- pure host arithmetic of the row-slab decomposition and of the launch /
 // halo-exchange schedule of one poisson_solve.  No HIP, no RCCL: this translation unit is what
 // the CPU (gloo, world_size 2) tests exercise through the C ABI (sfl_slab_rows,
-// sfl_sor_pass_plan, sfl_plan_poisson), and what the GPU executor in sfl_api.cpp walks.
+// sfl_sor_pass_plan, sfl_plan_poisson), and what the GPU executor in sor_executor.cpp walks.
 #pragma once
 #include <stdint.h>
 

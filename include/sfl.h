@@ -93,11 +93,12 @@ extern "C" {
                                      kernels                                                     */
 
 #define SFL_OPT_SOR_OVERLAP 8     /* slabs, kernel 2: 1 (default) = the halo exchanges of a solve run on a
-                                     second stream: a superstep's halo travels one launch early while the
-                                     owned rows of that launch are relaxed, its ghost rows are relaxed behind
-                                     the message (halo >= 2 x fuse; otherwise, and for the right-hand side:
-                                     cut-adjacent rows first / last around the message);
-                                     0 = every launch whole, exchanges in line                          */
+                                     second stream, in one of two schedules (SFL_OPT_SOR_ARRIVAL): in time and
+                                     counted on the device, or one launch early behind events -- a superstep's
+                                     halo then travels while the owned rows of that launch are relaxed, its ghost
+                                     rows are relaxed behind the message (halo >= 2 x fuse; shallower halos and
+                                     the right-hand side's exchange are awaited in line);
+                                     0 = every launch whole, every exchange in line                     */
 #define SFL_OPT_ADVECT_KERNEL 9   /* advection, divergence and gradient kernels: 0 = auto, 1 = one
                                      thread per cell reading its neighbours / texels from memory,
                                      2 = the window of a 64 x 32-cell tile staged in LDS (auto = 2
@@ -219,7 +220,7 @@ typedef struct sfl_plan_step {
  * as that launch needs for the owned rows (EXCHANGE.g_begin = its nsweeps, rows = halo - nsweeps);
  * that launch's output extends `what the next superstep needs` into the ghost rows, i.e. its passes
  * are repeated on the received rows.  An executor may run the owned rows of that launch while the
- * message travels and the ghost rows behind it (sfl_api.cpp run_poisson_overlapped does).
+ * message travels and the ghost rows behind it (csrc/sor_executor.cpp run_poisson_early does).
  * Writes at most `cap` steps, returns the total in *n_steps.  Pure arithmetic, no GPU needed;
  * the GPU executor walks exactly this program.                                               */
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,

@@ -18,7 +18,7 @@ OMEGA = np.float32(1.96)
 
 def plan_exchanges(sfl, dim_y, nranks, iters, fuse, halo=0, kernel=3):
     """Halo exchanges of one fused-kernel solve as the library plans it with an automatic (0) or given halo:
-    counted on the program sfl_plan_poisson returns (csrc/sfl_api.cpp effective_halo restated).  kernel 3 = exchanges in
+    counted on the program sfl_plan_poisson returns (csrc/sor_executor.cpp legacy_halo restated; the automatic depth is a timed choice: pass the solve's own).  kernel 3 = exchanges in
     time (the default executor, SFL_OPT_SOR_ARRIVAL), 2 = early exchanges where the halo is deep enough."""
     rows = min(b - a for a, b in (sfl.slab_rows(dim_y, nranks, r) for r in range(nranks)))
     h = halo or (64 if rows >= 1024 else 32)      # (callers pass last_solve_info()["halo"]: the automatic depth is a measured choice)
