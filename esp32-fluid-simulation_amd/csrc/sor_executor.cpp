@@ -68,10 +68,8 @@ bool small_grid(const sfl_context *c)
 // Only differences between depths matter: a deeper halo trades exchanges for redundantly relaxed ghost rows.
 static double modelled_solve_us(const sfl_context *c, int iters, int fuse, int halo, bool in_time)
 {
-    const int rows = min_owned_rows(c), nranks = c->nranks, mid = nranks > 2 ? 1 : 0;
+    const int nranks = c->nranks, mid = nranks > 2 ? 1 : 0;   // (a rank with a cut on both sides where the group has one)
     const std::vector<sfl_plan_step> prog = sfl::plan_poisson(c->gdim_y, nranks, mid, iters, fuse, in_time ? 3 : 2, halo, c->solve_tail);
-    int b = 0, e = 0;
-    sfl::slab_rows(c->gdim_y, nranks, mid, &b, &e);
     const double lat = c->exchange_latency_us, per_row = c->exchange_ns_per_row * 1e-3 * (c->dim_x / 8192.0);
     double us = 0.0, launch_us = 0.0;
     int launches = 0;
@@ -88,17 +86,16 @@ static double modelled_solve_us(const sfl_context *c, int iters, int fuse, int h
             const double msg = lat + st.rows * per_row;   // (measured on p: 4-byte rows; the right-hand side's are the same size)
             us += (per_launch > 2.0 * msg ? 0.6 : 1.0) * msg;
         }
-    (void)rows;
     return us;
 }
 
-// Halo depth of a solve's supersteps.  An explicit SFL_OPT_SOR_HALO is taken as given.  Automatic: the depth round 2 - 4 settled
+// Halo depth of a solve's supersteps.  An explicit SFL_OPT_SOR_HALO is taken as given.  Automatic: the depth rounds 2 - 4 settled
 // on with self-copies as the transport (64 rows on slabs of >= 1024 rows: 2 - 3 exchanges per 80-iteration solve, ~5 % extra
-// rows recomputed; 32 on thinner ones) -- unless the exchange has been measured and the model above predicts at least 3 % for
-// another depth: with RCCL's own kernels as the transport an exchange costs 25 - 30 us more than a copy
-// (profiles/r05_emulate_rccl.txt), and a real wire adds to that; 8192^2 on 8 GPUs then does better with ONE p exchange per
-// solve (80 rows) or none (160) than with two.  Every rank of a group sees the same measurement (its maximum over the ranks)
-// and the same thinnest slab, so all ranks resolve the same depth.
+// rows recomputed; 32 on thinner ones) is the starting point and the fallback; with RCCL's own kernels as the transport an
+// exchange costs a solve 10 - 17 us more than a copy (profiles/r05_emulate_rccl.txt) and a real wire adds to that -- 8192^2 on
+// 8 GPUs then does better with ONE p exchange per solve (80 rows) or none (160) than with two.  The model above names the
+// candidates, timed solves decide (choose_halo).  Every rank of a group sees the same measurement (its maximum over the ranks)
+// and the same thinnest slab, so all ranks name the same candidates.
 static int clamp_halo(const sfl_context *c, int fuse, int h)
 {
     const int thinnest = min_owned_rows(c);
