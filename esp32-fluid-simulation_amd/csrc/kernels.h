@@ -99,6 +99,7 @@ struct SorParams {
     float dx;
     float omega;
     float one_minus_omega;  // (1 - omega) evaluated in float on the host, poisson.cpp:98,111
+    float neg_quarter_omega;  // -0.25f * omega: the fused kernel's interior relaxation folds poisson.cpp:109's -0.25f into omega (sor_stream_core.h relax)
 };
 
 // Baseline: ONE colour pass, in place, over global rows [g_begin, g_end).

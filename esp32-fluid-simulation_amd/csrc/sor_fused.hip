@@ -135,7 +135,7 @@ __device__ __forceinline__ int relax_tile(float *p_out, const float *p_in, const
     };
     if (!SFL_PROBE_NO_EDGE && sor::tile_touches_boundary(t, rect, g.gdim_y)) {  // wave-uniform
         B bk = backend();
-        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega), bk.splat(prm.neg_quarter_omega)};
         const auto eca = bk.edge_cell(lane, x0, 0);
         const auto ecb = bk.edge_cell(lane, x0, 1);
         sor::stream_tile<B, NS, true, DX1, ZERO_IN>(bk, c, eca, ecb, r0, r1);
@@ -144,13 +144,13 @@ __device__ __forceinline__ int relax_tile(float *p_out, const float *p_in, const
     if (sor::tile_may_flip(t, rect)) {  // streamed top-down: pipeline index = -row
         B bk = backend();
         bk.row_sign = -1;
-        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+        sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega), bk.splat(prm.neg_quarter_omega)};
         const sor::EdgeCell<B> none{};
         sor::stream_tile<B, NS, false, DX1, ZERO_IN, true>(bk, c, none, none, 1 - r1, 1 - r0);
         return 2;
     }
     B bk = backend();
-    sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega)};
+    sor::Consts<B> c{bk.splat(prm.dx), bk.splat(prm.omega), bk.splat(prm.one_minus_omega), bk.splat(prm.neg_quarter_omega)};
     const sor::EdgeCell<B> none{};
     sor::stream_tile<B, NS, false, DX1, ZERO_IN>(bk, c, none, none, r0, r1);
     return 0;

@@ -78,7 +78,7 @@ struct RowFacts {  // wave-uniform
 
 template <class B>
 struct Consts {
-    typename B::V dx, omega, one_minus_omega;
+    typename B::V dx, omega, one_minus_omega, neg_quarter_omega;
 };
 
 // B::kPrefetch = rows in flight ahead of the pipeline (must divide 6, hence every RING)
@@ -95,27 +95,30 @@ struct Pipe {
 };
 
 // One relaxation (poisson.cpp:63-112).
-template <class B, bool EDGE, bool DX1>
+template <class B, bool EDGE>
 SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, typename B::V w,
                            typename B::V e, typename B::V s, typename B::V n, typename B::V d,
                            const EdgeCell<B> &ec, RowFacts rf)
 {
     using V = typename B::V;
-    V sum;
-    V k;
-    if (EDGE) {
-        const V z = rf.full ? ec.z_full : bk.splat(0.0f);
-        k = rf.full ? ec.k_full : ec.k_part;
-        sum = (((z + w) + e) + s) + n;
-    } else {
-        k = bk.splat(-0.25f);
-        sum = ((w + e) + s) + n;
+    const V rhs = d;   // fl(dx * d), formed when the row entered the ring (iterate)
+    if (!EDGE) {
+        // poisson.cpp:107-111 asks for fl(omega * fl(-0.25f * t)), t = dx * d - sum.  Scaling by -0.25 is exact unless the
+        // product underflows inexactly, and so is -0.25f * omega: fl(omega * (-0.25f * t)) == fl((-0.25f * omega) * t), ONE
+        // rounded multiplication instead of two -- 7 vector instructions per relaxation instead of 8, bit for bit the same
+        // result whenever t is a multiple of 2^-147, i.e. unless an operand (dx * d or a neighbour's p) is a nonzero number
+        // below 2^-124 = 4.7e-38.  (There the reference rounds -0.25f * t to a denormal first and the two products can differ
+        // by one unit of 2^-149: tests/test_gpu_parity.py test_folded_quarter_omega_at_the_edges_of_float, DESIGN 3.  An omega
+        // whose own quarter would underflow never gets here: host::sor_fold_is_exact sends that solve to the one-pass kernel.)
+        const V sum = ((w + e) + s) + n;
+        return c.one_minus_omega * own + c.neg_quarter_omega * (rhs - sum);
     }
-    const V rhs = DX1 ? d : c.dx * d;
+    const V z = rf.full ? ec.z_full : bk.splat(0.0f);
+    const V k = rf.full ? ec.k_full : ec.k_part;
+    const V sum = (((z + w) + e) + s) + n;
     const V gs = k * (rhs - sum);
-    V out = c.one_minus_omega * own + c.omega * gs;
-    if (EDGE) out = bk.select(bk.mask_and(ec.in, rf.in_dom), out, bk.splat(-0.0f));
-    return out;
+    const V out = c.one_minus_omega * own + c.omega * gs;
+    return bk.select(bk.mask_and(ec.in, rf.in_dom), out, bk.splat(-0.0f));
 }
 
 // Trips of a tile: the first ones are the pipeline's prologue.  Pass s (1 .. NS) only has to be
@@ -169,9 +172,11 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
         // receive the next load at once (otherwise the compiler keeps the old value alive in
         // them and has to drain all loads in flight at the loop back-edge to rotate registers)
         V a = bk.detach(pp.pa[Q]), b = bk.detach(pp.pb[Q]);
-        const V fa = pp.da[Q], fb = pp.db[Q];
-        bk.ring_store(U, 0, is_even(U) ? fa : fb);  // plane 0: d of the E cell
-        bk.ring_store(U, 1, is_even(U) ? fb : fa);  // plane 1: d of the O cell
+        // poisson.cpp:94 / :109 multiply dx * d anew in every relaxation -- the same two operands, the same rounded product every
+        // time: it is formed ONCE, here, and the ring holds fl(dx * d) (dx == 1: d itself, kernels without the multiplication)
+        const V fa = DX1 ? pp.da[Q] : c.dx * pp.da[Q], fb = DX1 ? pp.db[Q] : c.dx * pp.db[Q];
+        bk.ring_store(U, 0, is_even(U) ? fa : fb);  // plane 0: dx * d of the E cell
+        bk.ring_store(U, 1, is_even(U) ? fb : fa);  // plane 1: dx * d of the O cell
         bk.load_row(y + kPrefetch, pp.pa[Q], pp.pb[Q], pp.da[Q], pp.db[Q]);
         if (ZERO_IN) a = b = bk.splat(0.0f);  // poisson.cpp:117-119, fused
         if (EDGE) {  // cells outside the domain hold the additive identity
@@ -225,7 +230,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V e = ev ? oc : bk.from_upper_lane(oc);
             const V d = d_e[m];
             const RowFacts rf = bk.row_facts(r);
-            pp.E[i0] = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.O[FLIP ? ip : im], pp.O[FLIP ? im : ip], d,
+            pp.E[i0] = relax<B, EDGE>(bk, c, own, w, e, pp.O[FLIP ? ip : im], pp.O[FLIP ? im : ip], d,
                                            ev ? eca : ecb, rf);
         }
         // ---- O_m of row y - 2m ----
@@ -241,7 +246,7 @@ SFL_HD void iterate(B &bk, Pipe<B, NS> &pp, const Consts<B> &c, const EdgeCell<B
             const V e = ev ? bk.from_upper_lane(oc) : oc;
             const V d = d_o[m];
             const RowFacts rf = bk.row_facts(r);
-            const V res = relax<B, EDGE, DX1>(bk, c, own, w, e, pp.E[FLIP ? ip : im], pp.E[FLIP ? im : ip], d,
+            const V res = relax<B, EDGE>(bk, c, own, w, e, pp.E[FLIP ? ip : im], pp.E[FLIP ? im : ip], d,
                                               ev ? ecb : eca, rf);
             if (m < NS / 2) {
                 pp.O[i0] = res;
@@ -366,7 +371,10 @@ SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t) -
 // kMinEdgeRows; when even such a tile would outlast the interior ones by more than a fifth,
 // shortening cannot equalise anything (small grids: the warm-up rows dominate and the extra tiles
 // only cost parallelism, measured 1024^2: -30 %) and 0 is returned: keep the uniform tiling.
-constexpr int kEdgeRowCost16 = 10;
+#ifndef SFL_EDGE_ROW_COST16
+#define SFL_EDGE_ROW_COST16 10   // (a build-time knob for the sweep only: tools/recipes/build_variant.sh)
+#endif
+constexpr int kEdgeRowCost16 = SFL_EDGE_ROW_COST16;
 constexpr int kMinEdgeRows = 8;
 SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 {

@@ -207,7 +207,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             bk.tile_r0 = r0;
             bk.tile_r1 = r1;
             bk.stray_stores = &stray;
-            Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega)};
+            Consts<EmuBackend> c{bk.splat(dx), bk.splat(omega), bk.splat(1.0f - omega), bk.splat(-0.25f * omega)};
             const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
             const bool flipped = !edge && tile_may_flip(t, rect);
             const bool dx1 = dx == 1.0f;

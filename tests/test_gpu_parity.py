@@ -152,6 +152,32 @@ def test_signed_zero_and_zero_rhs(sfl, oracle):
                              f"fill {fill} kernel {k}")
 
 
+def test_folded_quarter_omega_at_the_edges_of_float(sfl, oracle):
+    """The fused kernel's interior relaxation multiplies once by -0.25f * omega where poisson.cpp:109-111 multiplies by -0.25f and
+    then by omega (csrc/sor_stream_core.h relax).  The same bits unless a quarter underflows INEXACTLY: an omega below 2^-124 goes
+    to the one-pass kernel (exact); a residual t = dx * d - sum has bits below 2^-147 only if one of its operands is a nonzero
+    number below 2^-124 (4.7e-38) -- then -0.25f * t is rounded once instead of twice, one unit of 2^-149 apart, which later
+    passes amplify like any perturbation.  Fields that live at the very bottom of the float range agree within north_star's
+    tolerance (1e-5 of the field's maximum) instead of bit for bit; everything above stays bit-exact."""
+    _, _, d = random_fields(300, 150, 21)
+    for omega in (np.float32(1e-39), np.float32(3e-38), np.float32(2.0 ** -124), np.float32(0.0), np.float32(-1.5)):
+        hp = sfl.HostPath(sor_kernel=2, sor_fuse=8)
+        assert_bit_equal(hp.poisson_solve(d, 1.0, 5, omega), oracle.poisson_solve(d, 1.0, 5, omega), f"omega {omega}")
+    for exp in (-60, -100):   # (no operand below 2^-124: a Gaussian sample is not 2^-24 small)
+        small = (d * np.float32(2.0 ** exp)).astype(np.float32)
+        assert_bit_equal(sfl.HostPath(sor_kernel=2, sor_fuse=8).poisson_solve(small, 1.0, 6, OMEGA),
+                         oracle.poisson_solve(small, 1.0, 6, OMEGA), f"right-hand side scaled by 2^{exp}")
+    for exp in (-118, -122, -126, -140):
+        tiny = (d * np.float32(2.0 ** exp)).astype(np.float32)
+        got = sfl.HostPath(sor_kernel=2, sor_fuse=8).poisson_solve(tiny, 1.0, 6, OMEGA).astype(np.float64)
+        want = oracle.poisson_solve(tiny, 1.0, 6, OMEGA)
+        apart = np.max(np.abs(got - want.astype(np.float64)))
+        # 1e-5 relative (north_star); where the whole field is denormal a unit of 2^-149 is already more than that: a few units
+        assert apart <= max(1e-5 * np.max(np.abs(want)), 64 * 2.0 ** -149), f"2^{exp}: {apart / 2.0 ** -149} units of 2^-149 apart"
+        # ... and the one-pass kernel, which multiplies twice, needs no such allowance
+        assert_bit_equal(sfl.HostPath(sor_kernel=1).poisson_solve(tiny, 1.0, 6, OMEGA), want, f"one-pass kernel, 2^{exp}")
+
+
 def test_iters_zero_gives_zero_pressure(hip):
     d = np.ones((9, 12), np.float32)
     p = hip.poisson_solve(d, 1.0, 0, OMEGA)

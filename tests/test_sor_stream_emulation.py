@@ -3,6 +3,7 @@ is compiled from) executed lane-by-lane by tests/cpp/sor_stream_emu.cpp and comp
 oracle bit for bit.  Pipeline registers, the LDS ring and every clamped load are NaN-poisoned
 in the emulator, so a stale or out-of-tile read cannot go unnoticed."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -18,9 +19,12 @@ _F = C.POINTER(C.c_float)
 @pytest.fixture(scope="module")
 def emu():
     d = os.path.join(ROOT, "tests", "cpp")
-    so = os.environ.get("SFL_EMU_LIB") or os.path.join(d, "libsor_stream_emu.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", d, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    so = os.environ.get("SFL_EMU_LIB")
+    if not so:   # (make every time: a library older than sor_stream_core.h would test yesterday's pipeline)
+        so = os.path.join(d, "libsor_stream_emu.so")
+        with open(os.path.join(d, ".emu_build.lock"), "w") as lock:   # (pytest -n: one worker builds, the others wait)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.run(["make", "-C", d, "-j4", so], check=True, stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
     lib.emu_sor_fused.restype = C.c_int

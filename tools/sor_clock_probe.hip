@@ -81,7 +81,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e1));
     const sfl::Slab g{dim_x, dim_y, 0, dim_y};
     const sfl::SorRows rows{0, dim_y, 0, 0};
-    sfl::SorParams prm{1.0f, 1.96f, 1.0f - 1.96f};
+    sfl::SorParams prm{1.0f, 1.96f, 1.0f - 1.96f, -0.25f * 1.96f};
     const int alternate = getenv("PROBE_ALTERNATE") ? atoi(getenv("PROBE_ALTERNATE")) : 0;
     int n_launch = 0;
     auto launch = [&](float *out, const float *in) {
