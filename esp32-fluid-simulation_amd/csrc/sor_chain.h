@@ -169,7 +169,7 @@ hipError_t launch_chain_variant(hipStream_t s, float *pa, float *pb, const float
     for (int i = 0; i < n_steps; ++i) {
         const ChainStep &st = steps[i];
         int rpc = rows_per_chunk > st.g_end - st.g_begin ? st.g_end - st.g_begin : rows_per_chunk;
-        if (rpc <= 0) rpc = auto_rows_per_chunk<B>(g, st.g_begin, st.g_end, NS, resident, device_simds());
+        if (rpc <= 0) rpc = auto_rows_per_chunk<B>(g, st.g_begin, st.g_end, NS, resident, device_simds(), sor::kEdgeRowCost16);
         sor::Tiling t = sor::make_tiling(NS, B::kTileCols, B::kColAlign, g.dim_x, g.gdim_y, st.g_begin, st.g_end, rpc,
                                          sor::kEdgeRowCost16, kFlipTiles ? 1 + (st.sweep & 1) : 0);
         t.rotate = 0;

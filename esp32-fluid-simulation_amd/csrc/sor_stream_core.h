@@ -375,6 +375,7 @@ SFL_HD int strip_x0(const Tiling &t, int strip) { return strip * strip_step(t) -
 #define SFL_EDGE_ROW_COST16 10   // (a build-time knob for the sweep only: tools/recipes/build_variant.sh)
 #endif
 constexpr int kEdgeRowCost16 = SFL_EDGE_ROW_COST16;
+constexpr int kEdgeRowCostQueued16 = 8;   // launches with more tiles than wave slots (sor_fused.hip launch_variant)
 constexpr int kMinEdgeRows = 8;
 SFL_HD int balanced_edge_rows(int rows_per_chunk, int ns, int sixteenths)
 {

@@ -182,7 +182,7 @@ int main(int argc, char **argv)
     {   // the slowest waves and what they were streaming (the tiling the launcher chose, recomputed here)
         using B = sfl::Lane2<PROBE_NS, true, false, false>;
         const int waves = sfl::resident_waves<B, PROBE_NS, true, false>();
-        const int use_rpc = rpc > 0 ? rpc : sfl::auto_rows_per_chunk<B>(g, 0, dim_y, PROBE_NS, waves, sfl::device_simds());
+        const int use_rpc = rpc > 0 ? rpc : sfl::auto_rows_per_chunk<B>(g, 0, dim_y, PROBE_NS, waves, sfl::device_simds(), sfl::sor::kEdgeRowCost16);
         const sfl::sor::Tiling t = sfl::sor::make_tiling(PROBE_NS, B::kTileCols, B::kColAlign, dim_x, dim_y, 0, dim_y, use_rpc,
                                                          sfl::sor::kEdgeRowCost16, 1);
         printf("tiling: rows per tile %d (boundary strips %d, first / last chunk %d / %d), %d strips (%d inner), %d tiles\n",
