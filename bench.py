@@ -943,7 +943,9 @@ def run_rank(args):
                      "note": "the package runs at its 1400 W power cap under this kernel and clocks 1.6-2.1 GHz depending "
                              "on the box (s_memtime against s_memrealtime in every wave, rocm-smi: "
                              "profiles/r03_clock_probe_ns16_8192.txt, r03_clock_smi_during_kernel.txt); the peak above "
-                             "is the nominal 2.4 GHz"},
+                             "is the nominal 2.4 GHz; 'useful' counts the reference's 8 rounded operations per relaxation "
+                             "(poisson.cpp:107-111), of which the kernel's interior path issues 7 (-0.25f folded into omega, "
+                             "csrc/sor_stream_core.h relax)"},
         }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",

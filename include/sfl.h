@@ -57,7 +57,13 @@ extern "C" {
 
 /* ---- tunables (sfl_set_option / sfl_get_option) ------------------------------------------ */
 #define SFL_OPT_SOR_KERNEL 0      /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
-                                     2 = fused multi-pass streaming kernel                       */
+                                     2 = fused multi-pass streaming kernel.  Both give the reference's
+                                     bits; kernel 2 multiplies once by -0.25f * omega where poisson.cpp:109-111
+                                     multiplies twice, which is the same rounding unless an operand (dx * d or
+                                     a neighbour's p) is a nonzero number below 2^-124 = 4.7e-38 -- fields that
+                                     live down there agree within units of 2^-149 instead;
+                                     kernel 1 has no such condition, and an omega whose quarter underflows
+                                     is solved by it whatever this option says                    */
 #define SFL_OPT_SOR_FUSE 1        /* colour passes fused per launch by kernel 2: even, 2..16, or
                                      0 = auto (16 on slabs of >= 12 M cells, 10 from 3 M, else 8) */
 #define SFL_OPT_ADVECT_HALO 2     /* slabs: rows of the advected field exchanged per side.  0 (default) =
