@@ -321,6 +321,12 @@ def parse_args(argv=None):
     ap.add_argument("--arrival-in-time", action="store_true",
                     help="SFL_OPT_SOR_ARRIVAL = 1: exchanges in time, counted on the device, also where the library would not "
                          "choose them by itself (RCCL ranks whose peers are other processes)")
+    ap.add_argument("--share-device", type=int, default=None, metavar="D",
+                    help="multi-rank runs on a box with FEWER GPUs than ranks: every rank process uses device D and tells RCCL it "
+                         "is a host of its own (NCCL_HOSTID), so the N processes form a real N-rank communicator over RCCL's "
+                         "socket transport on the loopback interface.  Proves the multi-process path (rendezvous, "
+                         "ncclCommInitRank, matched send / recv between processes, the collective decisions, parity of every "
+                         "rank's rows); its timings mean nothing (one GPU, host-staged messages) and the line says so")
     ap.add_argument("--launch-timeout", type=float, default=400.0,
                     help="multi-GPU runs: seconds after which the rank processes of ONE attempt are stopped (the launcher then "
                          "starts fresh ranks with the next exchange schedule; all attempts together stay under 1500 s)")
@@ -582,8 +588,15 @@ def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if "SFL_BENCH_DEVICE" in os.environ:   # bring-up aid: several ranks on one device
-        local_rank = int(os.environ["SFL_BENCH_DEVICE"])
+    shared_device = args.share_device if args.share_device is not None else os.environ.get("SFL_BENCH_DEVICE")
+    if shared_device is not None:   # --share-device: several ranks on one device
+        local_rank = int(shared_device)
+        # RCCL refuses two ranks of a communicator on one device OF ONE HOST ("Duplicate GPU detected"): every rank says it is
+        # a host of its own, and the ranks talk through RCCL's socket transport over the loopback interface -- a real N-rank
+        # communicator of N processes on a one-GPU box.  Correctness of the multi-process path, not its speed.
+        os.environ.setdefault("NCCL_HOSTID", f"sfl-shared-device-rank-{rank}")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     args.gpus = world
 
     sfl = importlib.import_module(PKG)
@@ -604,11 +617,12 @@ def run_rank(args):
             time.sleep(3600)
         rdzv.barrier()
         top = rdzv.max([float(rank), 1.0])
-        ranks = rdzv.all_gather({"rank": rank, "token": token.hex()})
+        ranks = rdzv.all_gather({"rank": rank, "token": token.hex(), "device": local_rank, "hostid": os.environ.get("NCCL_HOSTID")})
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank": top[0], "mode": mode_of(args),
                               "tokens_agree": len({r["token"] for r in ranks}) == 1,
-                              "ranks": [r["rank"] for r in ranks]}), flush=True)
+                              "ranks": [r["rank"] for r in ranks], "devices": [r["device"] for r in ranks],
+                              "rccl_host_ids": [r["hostid"] for r in ranks]}), flush=True)
         rdzv.barrier()
         rdzv.close()
         return 0
@@ -956,7 +970,11 @@ def run_rank(args):
             "config": {"workload": f"poisson_solve {size}x{dim_y} fp32, {iters} red-black SOR iters/step, "
                                    f"omega 1.96, dx 1, rhs = divergence of a seeded velocity field",
                        "grid": [size, dim_y], "iters": iters,
-                       "parallelism": "1 GPU" if world == 1 else f"row-slab x{world}, RCCL halo exchange",
+                       "parallelism": "1 GPU" if world == 1 else f"row-slab x{world}, RCCL halo exchange" +
+                                      (f"; ALL {world} RANK PROCESSES ON DEVICE {local_rank} (--share-device: RCCL's socket transport "
+                                       "over loopback between them) -- a correctness run of the multi-process path, its timings "
+                                       "say nothing about xGMI or scaling" if shared_device is not None and world > 1 else ""),
+                       **({"physical_gpus": 1, "ranks_share_device": local_rank} if shared_device is not None and world > 1 else {}),
                        "sor_launches_per_solve": info["launches"],
                        "supersteps_in_chained_launches": info["chained"],
                        "halo_exchanges_per_solve": info["exchanges"],

@@ -62,7 +62,19 @@ def test_bench_self_launch_as_typed():
     assert r.returncode == 0, r.stderr
     out = _json_line(r.stdout)
     assert out == {"dry_run": True, "n_gpus": 3, "max_rank": 2.0, "mode": "in-time", "tokens_agree": True, "ranks": [0, 1, 2],
-                   "exchange_mode": "in-time", "fallback_from": []}
+                   "devices": [0, 1, 2], "rccl_host_ids": [None, None, None], "exchange_mode": "in-time", "fallback_from": []}
+
+
+def test_share_device_gives_every_rank_the_device_and_a_host_id_of_its_own():
+    """`--share-device D`: N rank processes on ONE device form a real N-rank RCCL communicator only if RCCL takes them for ranks
+    on different hosts (it refuses duplicate devices of one host): every rank must carry its own NCCL_HOSTID and use device D."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--share-device", "0", "--dry-run"],
+                       capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NCCL_HOSTID")})
+    assert r.returncode == 0, r.stderr
+    out = _json_line(r.stdout)
+    assert out["devices"] == [0, 0, 0] and out["ranks"] == [0, 1, 2]
+    assert len(set(out["rccl_host_ids"])) == 3 and None not in out["rccl_host_ids"]
 
 
 def test_bench_under_torch_distributed_run():
