@@ -569,7 +569,7 @@ int sfl_synchronize(sfl_context *ctx)
                 HIP_TRY(hipMemset(c->halo_flag + 2, 0, sizeof(int)));
                 // bits: 1 a tile of a launch, 4 a tile of a chained launch, 8 the exchange stream (for the sender count) waited
                 // for a halo message; 2 a tile of a chained launch for the tiles around it
-                rc = fail(SFL_ERR_HIP, "slab %d/%d: a wait inside a solve lasted longer than %.0f s (waits 0x%x; arrival "
+                rc = fail(SFL_ERR_HIP, "slab %d/%d: a wait inside a solve lasted longer than %g s (waits 0x%x; arrival "
                           "count %d of %d): the pressure field is not valid", c->rank, c->nranks,
                           halo_timeout_us(c) / 1e6, words[2], words[1], c->arrival_epoch);
             }

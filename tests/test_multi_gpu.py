@@ -93,3 +93,15 @@ def test_rccl_ranks_as_processes_on_one_device(nranks, size, iters, halo, mode):
     # RCCL's own word for it: a communicator of `nranks` ranks, reached over the socket transport
     assert f"nranks {nranks}" in log or f"nRanks {nranks:02d}" in log, log[-3000:]
     assert "NET/Socket" in log, log[-3000:]
+
+
+def test_a_real_time_out_makes_the_launcher_fall_back_with_fresh_rccl_ranks():
+    """End to end, nothing simulated: four rank processes on one device, exchanges in time with a limit (1 ms) no message between
+    time-sliced processes can meet -- a wait inside a solve gives up on a real RCCL rank, that rank fails loudly, the launcher stops
+    the others and starts FRESH ranks behind events, whose result is the reference's."""
+    if _devices() < 1:
+        pytest.skip("needs a GPU")
+    out, log = _run_bench(4, 2048, 40, 0, "", steps=6, extra=["--share-device", "0", "--halo-timeout-ms", "1"])
+    assert out["exchange_mode"] == "by-event", (out["exchange_mode"], out["fallback_from"])
+    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
+    assert "a wait inside a solve lasted longer than" in out["fallback_from"][0]["why"]
