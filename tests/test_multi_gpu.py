@@ -18,6 +18,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+def _needs_loopback():
+    """the ranks of a shared device talk over RCCL's socket transport on `lo` (NCCL_SOCKET_IFNAME): no such interface, no test"""
+    import socket
+    if "lo" not in [name for _, name in socket.if_nameindex()]:
+        pytest.skip("no loopback interface for RCCL's socket transport")
+
+
 def _devices():
     return importlib.import_module("esp32-fluid-simulation_amd").device_count()
 
@@ -83,6 +90,7 @@ def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, mode):
 def test_rccl_ranks_as_processes_on_one_device(nranks, size, iters, halo, mode):
     if _devices() < 1:
         pytest.skip("needs a GPU")
+    _needs_loopback()
     extra = ["--share-device", "0"]
     if "--arrival-in-time" in MODES[mode]:
         extra += ["--halo-timeout-ms", "15000"]   # (a lost message is to end as an error, not as a kernel that spins for minutes)
@@ -101,6 +109,7 @@ def test_a_real_time_out_makes_the_launcher_fall_back_with_fresh_rccl_ranks():
     the others and starts FRESH ranks behind events, whose result is the reference's."""
     if _devices() < 1:
         pytest.skip("needs a GPU")
+    _needs_loopback()
     out, log = _run_bench(4, 2048, 40, 0, "", steps=6, extra=["--share-device", "0", "--halo-timeout-ms", "1"])
     assert out["exchange_mode"] == "by-event", (out["exchange_mode"], out["fallback_from"])
     assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]

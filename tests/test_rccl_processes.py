@@ -21,6 +21,9 @@ pytestmark = pytest.mark.gpu
 def run_ranks(world, scenario, seed, seconds=None, timeout=600):
     if importlib.import_module("esp32-fluid-simulation_amd").device_count() < 1:
         pytest.skip("needs a GPU")
+    import socket
+    if "lo" not in [name for _, name in socket.if_nameindex()]:   # (NCCL_SOCKET_IFNAME=lo: RCCL's socket transport between the ranks)
+        pytest.skip("no loopback interface for RCCL's socket transport")
     private = tempfile.mkdtemp(prefix="sfl_rccl_test_")
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NCCL_HOSTID")}
     base.update({"WORLD_SIZE": str(world), "SFL_RDZV_KEY": f"pytest_{os.getpid()}_{scenario}_{world}", "SFL_RDZV_DIR": private})

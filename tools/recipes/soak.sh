@@ -23,7 +23,8 @@ for leg in $LEGS; do case $leg in
   copy)      run python tools/soak_transport.py 64 $SECS copy;;
   unaligned) run python tools/unaligned_stress.py $SECS 1; run python tools/unaligned_stress.py $((SECS / 2)) 0;;
   chain)     GPU_MAX_HW_QUEUES=8 run python tools/chain_stress.py $SECS 17;;
-  ranks)     for w in 2 3 4; do run python tests/rccl_rank_worker.py --spawn $w soak $((70 + w)) $((SECS / 2)); done;;
+  ranks)     for w in 2 3 4; do run python tests/rccl_rank_worker.py --spawn $w soak $((70 + w)) $((SECS / 2)); done
+             run python tests/rccl_rank_worker.py --spawn 3 soak 79 $((SECS / 2)) big;;
 esac; done
 cat $OUT
 exit $rc
