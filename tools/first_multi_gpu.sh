@@ -17,6 +17,10 @@ mkdir -p $O
 NG=$(python3 -c "import importlib; print(importlib.import_module('esp32-fluid-simulation_amd').device_count())")
 echo "visible GPUs: $NG" | tee $O/summary.txt
 if [ "$NG" -lt 2 ]; then echo "needs at least 2 GPUs" | tee -a $O/summary.txt; exit 1; fi
+# (0. the same N processes and N-rank communicator on GPU 0 alone, over RCCL's socket transport -- what the one-GPU boxes could show,
+#  profiles/r05_rccl_ranks_on_one_device.txt: if THIS fails here the trouble is not the wire)
+timeout 600 python3 bench.py --gpus 4 --share-device 0 --size 2048 --iters 40 --steps 6 --warmup 1 --sim-steps 1 --no-priming > $O/bench_shared_device_n4.json 2> $O/bench_shared_device_n4.err \
+    && echo "4 ranks on device 0 over sockets: ok" | tee -a $O/summary.txt || echo "4 ranks on device 0 over sockets: FAILED (see $O/bench_shared_device_n4.err)" | tee -a $O/summary.txt
 ( time python3 -m pytest tests/test_multi_gpu.py -m gpu -x -q ) > $O/pytest_multi_gpu.log 2>&1
 tail -3 $O/pytest_multi_gpu.log | tee -a $O/summary.txt
 for n in 1 2 4 8; do
