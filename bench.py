@@ -280,6 +280,11 @@ def parse_args(argv=None):
     ap.add_argument("--dim-y", type=int, default=0, help="rows (default: size); experiments only")
     ap.add_argument("--fuse", type=int, default=0, help="SOR half-sweeps fused per launch (0 = library default)")
     ap.add_argument("--sor-kernel", type=int, default=0)
+    ap.add_argument("--sor-fold", action="store_true",
+                    help="SFL_OPT_SOR_FOLD = 1 for the TIMED solves: the interior relaxation's one product by -0.25f * omega (opt-in "
+                         "arithmetic, not the reference's bits on sparse fields; the line's `numerics` says so).  Without it the "
+                         "folded arithmetic is still measured once, after everything else, as numerics.value_with_fold")
+    ap.add_argument("--no-fold-leg", action="store_true", help="skip that extra measurement")
     ap.add_argument("--sor-rows", type=int, default=0)
     ap.add_argument("--sor-halo", type=int, default=0, help="rows of p exchanged per superstep (0 = auto)")
     ap.add_argument("--lane-cells", type=int, default=0, help="cells per lane of the fused kernel (0 auto, 2)")
@@ -665,6 +670,8 @@ def run_rank(args):
             s.set_option(opt, val)
     if args.no_fuse_projection:
         s.set_option(capi.OPT_FUSE_PROJECTION, 0)
+    if args.sor_fold:
+        s.set_option(capi.OPT_SOR_FOLD, 1)
     if world > 1:
         uid = rdzv.broadcast_bytes(sfl.comm_unique_id() if rank == 0 else None)
         # RCCL prints a version banner on stdout while the communicator comes up; keep stdout
@@ -823,6 +830,17 @@ def run_rank(args):
     if world == 1 and args.sim_steps > 0:
         op_us = gpu_operator_times(s, iters, cells)
 
+    # ---- the opt-in arithmetic beside the default (numerics.value_with_fold): the same W + K region with SFL_OPT_SOR_FOLD flipped,
+    # after everything the line's other numbers come from; one GPU only (RCCL ranks would have to agree on the option collectively)
+    other_arith = None
+    if world == 1 and not emulate and not args.no_fold_leg:
+        s.set_option(capi.OPT_SOR_FOLD, 0 if args.sor_fold else 1)
+        for _ in range(max(priming, 4)):
+            s.poisson_solve(1.0, iters, omega)
+        el2, ev2 = timed_region()
+        other_arith = {"value": cells * iters * args.steps / el2, "ms_per_solve_hip_events": ev2 / args.steps}
+        s.set_option(capi.OPT_SOR_FOLD, 1 if args.sor_fold else 0)
+
     # ---- parity: the reference CPU loop on the downloaded right-hand side ----------------------
     if want_parity:
         if world == 1:
@@ -958,8 +976,8 @@ def run_rank(args):
                              "on the box (s_memtime against s_memrealtime in every wave, rocm-smi: "
                              "profiles/r03_clock_probe_ns16_8192.txt, r03_clock_smi_during_kernel.txt); the peak above "
                              "is the nominal 2.4 GHz; 'useful' counts the reference's 8 rounded operations per relaxation "
-                             "(poisson.cpp:107-111), of which the kernel's interior path issues 7 (-0.25f folded into omega, "
-                             "csrc/sor_stream_core.h relax)"},
+                             "(poisson.cpp:107-111); the kernel's interior path issues those 8 (7 with --sor-fold: -0.25f "
+                             "folded into omega, csrc/sor_stream_core.h relax)"},
         }
         out = {
             "metric": "cell-iters/sec (SOR sweep)", "value": value, "unit": "cell-iters/s",
@@ -981,6 +999,23 @@ def run_rank(args):
                        "exchange_schedule": SCHEDULES.get(schedule, schedule),
                        "halo_rows_per_superstep": info["halo"], "measured_exchange_latency_us": exchange_us,
                        "half_sweeps_fused_per_launch": info["fuse"]},
+            # which arithmetic `value` was measured with, and what the other one would give
+            "numerics": {
+                "sor_fold": 1 if args.sor_fold else 0,
+                "interior_relaxation": ("(1 - omega) * p + (-0.25f * omega) * t, ONE product where poisson.cpp:109-111 has two: "
+                                        "SFL_OPT_SOR_FOLD = 1, opt-in; the reference's bits only where no operand of t is a nonzero "
+                                        "number below 2^-124 (dense fields: yes; the front of a sparsely forced field: no)")
+                if args.sor_fold else
+                ("(1 - omega) * p + omega * (-0.25f * t) with every product rounded on its own, as poisson.cpp:107-111 "
+                 "writes it: the library's default, the reference's bits on every input (dense, sparse, denormal)"),
+                "contract": "fp32 fields bit for bit (north_star allows 1e-5 relative), UQ32 / index / interpolation bit-exact; "
+                            "tests/test_gpu_parity.py test_quiescent_* hold the sparse-forcing case at 8192^2 x 80",
+                **({("value_default_arithmetic" if args.sor_fold else "value_with_fold"): other_arith["value"],
+                    ("ms_per_solve_default_arithmetic" if args.sor_fold else "ms_per_solve_with_fold"):
+                    other_arith["ms_per_solve_hip_events"],
+                    "fold_speedup": (other_arith["value"] / value) if not args.sor_fold else (value / other_arith["value"])}
+                   if other_arith else {}),
+            },
             "parity": parity,
             **({"sim_step_parity": step_parity} if step_parity is not None else {}),
             "roofline": roofline,

@@ -28,6 +28,7 @@ OPT_HALO_TIMEOUT_MS = 18
 OPT_EXCHANGE_SCHEDULE = 19
 OPT_MEASURED_WIRE_US = 20
 OPT_LAST_HALO = 21
+OPT_SOR_FOLD = 22
 CHANNEL_F32, CHANNEL_UQ32 = 0, 1
 STEP_EXCHANGE, STEP_SOR, STEP_ZERO = 1, 2, 3
 UNIQUE_ID_BYTES = 128

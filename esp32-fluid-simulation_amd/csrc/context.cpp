@@ -415,6 +415,9 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_STEP_SEAMS:
             c->opt_step_seams = value ? 1 : 0;
             return SFL_OK;
+        case SFL_OPT_SOR_FOLD:
+            c->opt_sor_fold = value ? 1 : 0;
+            return SFL_OK;
         case SFL_OPT_SOR_CHAIN:
             if (value < -1) return fail(SFL_ERR_INVALID, "SFL_OPT_SOR_CHAIN must be -1 (auto), 0, 1 or a number of waves >= 8");
             c->opt_sor_chain = value;   // >= 8: on, with at most that many waves per chain (several tiles per wave: a test aid)
@@ -454,6 +457,7 @@ int sfl_get_option(sfl_context *c, int option, int *value)
     if (!c || !value) return fail(SFL_ERR_INVALID, "NULL argument");
     switch (option) {
         case SFL_OPT_SOR_KERNEL: *value = c->opt_sor_kernel; return SFL_OK;
+        case SFL_OPT_SOR_FOLD: *value = c->opt_sor_fold; return SFL_OK;
         case SFL_OPT_SOR_FUSE: *value = c->opt_sor_fuse; return SFL_OK;
         case SFL_OPT_ADVECT_HALO: *value = c->opt_advect_halo; return SFL_OK;
         case SFL_OPT_SOR_ROWS: *value = c->opt_sor_rows; return SFL_OK;

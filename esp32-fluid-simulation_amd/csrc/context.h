@@ -206,7 +206,7 @@ struct sfl_context {
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
         opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = -1,
-        opt_step_seams = 1, opt_sor_chain = 0, opt_halo_timeout_ms = 0;
+        opt_step_seams = 1, opt_sor_chain = 0, opt_halo_timeout_ms = 0, opt_sor_fold = 0;
 
     // how halo rows reach the neighbouring slabs (transport.h); null on a whole-domain context and on a slab that has
     // not been attached / linked yet.  `group` = the same object when it is an in-process group of virtual ranks.
@@ -260,7 +260,7 @@ int check_wait_error(sfl_context *c);
 
 // ---- sor_executor.cpp ----
 int run_poisson(sfl_context *ctx, float dx, int iters, float omega);
-SorParams sor_params(float dx, float omega);
+SorParams sor_params(const sfl_context *c, float dx, float omega);
 // one workgroup, fields in LDS (small_grid.hip): may this context take that path?
 bool small_grid(const sfl_context *c);
 // halo timeout of the waits inside this context's launches, microseconds (kernels.h HaloWait::timeout_us)

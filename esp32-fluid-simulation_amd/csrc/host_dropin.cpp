@@ -49,6 +49,7 @@ struct HostCtx {
             cached = true;
             sfl_context fresh;  // option defaults
             c->opt_sor_kernel = fresh.opt_sor_kernel;
+            c->opt_sor_fold = fresh.opt_sor_fold;
             c->opt_sor_fuse = fresh.opt_sor_fuse;
             c->opt_sor_rows = fresh.opt_sor_rows;
             c->opt_sor_lane_cells = fresh.opt_sor_lane_cells;

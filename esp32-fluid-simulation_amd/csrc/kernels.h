@@ -99,7 +99,10 @@ struct SorParams {
     float dx;
     float omega;
     float one_minus_omega;  // (1 - omega) evaluated in float on the host, poisson.cpp:98,111
-    float neg_quarter_omega;  // -0.25f * omega: the fused kernel's interior relaxation folds poisson.cpp:109's -0.25f into omega (sor_stream_core.h relax)
+    float neg_quarter_omega;  // -0.25f * omega, used only when `fold` is set
+    int fold;                 // SFL_OPT_SOR_FOLD: 1 = the fused kernel's interior relaxation multiplies ONCE, by -0.25f * omega, where
+                              // poisson.cpp:109-111 multiplies by -0.25f and then by omega (sor_stream_core.h relax has the condition under
+                              // which that is the same bits); 0 (default) = two products, the reference's bits on every input
 };
 
 // Baseline: ONE colour pass, in place, over global rows [g_begin, g_end).

@@ -29,7 +29,7 @@ static int small_grid_step(sfl_context *c, float dt, float dx, int iters, float 
     a.iters = iters;
     a.dt = dt;
     a.two_dx_inv = 1.0f / (2.0f * dx);  // finitediff.cpp:36, :78-79
-    a.prm = sor_params(dx, omega);
+    a.prm = sor_params(c, dx, omega);
     a.force_cells = c->d_force_cells;
     a.force_vel = c->d_force_vel;
     a.n_forces = n_forces;

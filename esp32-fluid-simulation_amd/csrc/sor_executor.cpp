@@ -12,13 +12,18 @@
 namespace sfl {
 namespace host {
 
-sfl::SorParams sor_params(float dx, float omega)
+// The folded interior relaxation (SFL_OPT_SOR_FOLD, sor_stream_core.h relax) multiplies by -0.25f * omega: that quarter must itself be
+// exact, i.e. must not underflow -- an omega below 2^-124 is solved with both products whatever the option says.
+static bool quarter_omega_is_exact(float omega) { return (-0.25f * omega) * -4.0f == omega; }
+
+sfl::SorParams sor_params(const sfl_context *c, float dx, float omega)
 {
     sfl::SorParams prm;
     prm.dx = dx;
     prm.omega = omega;
     prm.one_minus_omega = 1.0f - omega;  // (1 - omega) in float, poisson.cpp:98,111
-    prm.neg_quarter_omega = -0.25f * omega;  // exact (a power of two) unless it underflows: sor_fold_is_exact
+    prm.neg_quarter_omega = -0.25f * omega;
+    prm.fold = c->opt_sor_fold && quarter_omega_is_exact(omega) ? 1 : 0;
     return prm;
 }
 
@@ -639,30 +644,10 @@ int run_poisson_overlapped(sfl_context *ctx, const std::vector<sfl_context *> &p
     return rc;
 }
 
-// The fused kernel's interior relaxation multiplies by -0.25f * omega where poisson.cpp:109-111 multiplies by -0.25f and then by
-// omega (sor_stream_core.h relax): the same bits as long as that quarter is exact, i.e. does not underflow.
-static bool sor_fold_is_exact(float omega) { return (-0.25f * omega) * -4.0f == omega || omega != omega; }
-
-static int run_poisson_with_kernel(sfl_context *ctx, float dx, int iters, float omega);
-
 int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
 {
     if (iters < 0) return fail(SFL_ERR_INVALID, "iters must be >= 0 (got %d)", iters);
-    if (sor_fold_is_exact(omega)) return run_poisson_with_kernel(ctx, dx, iters, omega);
-    // an omega below 2^-124 (every rank of a group is handed the same one): this solve by the one-pass kernel, which multiplies twice
-    std::vector<sfl_context *> peers = peers_of(ctx);
-    std::vector<int> asked;
-    for (sfl_context *c : peers) {
-        asked.push_back(c->opt_sor_kernel);
-        c->opt_sor_kernel = 1;
-    }
-    const int rc = run_poisson_with_kernel(ctx, dx, iters, omega);
-    for (size_t k = 0; k < peers.size(); ++k) peers[k]->opt_sor_kernel = asked[k];
-    return rc;
-}
 
-static int run_poisson_with_kernel(sfl_context *ctx, float dx, int iters, float omega)
-{
     std::vector<sfl_context *> peers = peers_of(ctx);
     SFL_TRY(resolve_schedule(ctx));
     const int fuse = effective_fuse(ctx), kernel = effective_kernel(ctx);
@@ -687,7 +672,7 @@ static int run_poisson_with_kernel(sfl_context *ctx, float dx, int iters, float 
         c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
-    const sfl::SorParams prm = sor_params(dx, omega);
+    const sfl::SorParams prm = sor_params(ctx, dx, omega);
     if (small_grid(ctx)) {  // one workgroup, p and d in LDS, every iteration in one launch
         SFL_TRY(use_device(ctx));
         HIP_TRY(sfl::launch_small_solve(ctx->stream, ctx->p, ctx->div, ctx->dim_x, ctx->gdim_y, iters, prm));

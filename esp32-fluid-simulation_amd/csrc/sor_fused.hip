@@ -415,7 +415,7 @@ hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float
     return hipErrorInvalidValue;
 }
 
-template <int NS, bool ZERO_IN>
+template <int NS, bool ZERO_IN, bool FOLD>
 hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                        SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
@@ -425,49 +425,62 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     if (can2v) {
         // written through when sender tiles publish rows of this launch while it runs (see Lane2)
         if (wait && wait->done)
-            return launch_dx<Lane2<NS, true, ZERO_IN, 16>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+            return launch_dx<Lane2<NS, true, ZERO_IN, 16, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
         // non-temporal stores once the slab's arrays no longer fit the caches
         if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
-            return launch_dx<Lane2<NS, true, ZERO_IN, 2>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
-        return launch_dx<Lane2<NS, true, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+            return launch_dx<Lane2<NS, true, ZERO_IN, 2, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        return launch_dx<Lane2<NS, true, ZERO_IN, 0, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
     }
-    return launch_dx<Lane2<NS, false, ZERO_IN>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+    return launch_dx<Lane2<NS, false, ZERO_IN, 0, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 }
 
-template <int NS>
+template <int NS, bool FOLD>
 hipError_t launch_ns(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                      SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
 {
     if (p_in == nullptr)
-        return launch_lane<NS, true>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
-    return launch_lane<NS, false>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        return launch_lane<NS, true, FOLD>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+    return launch_lane<NS, false, FOLD>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 }
 
 }  // namespace
 
-// One non-template entry per fuse depth and per half (dx == 1 / any dx); the depths and halves are spread over
-// translation units (SFL_NS_GROUP = 0..5, SFL_DX_PART = 0 / 1, see csrc/Makefile) so that they compile in parallel.
+// One non-template entry per fuse depth, per half (dx == 1 / any dx) and per arithmetic (exact / folded quarter); the depths, halves
+// and arithmetics are spread over translation units (SFL_NS_GROUP = 0..5, SFL_DX_PART = 0 / 1, SFL_FOLD_PART = 0 / 1, see
+// csrc/Makefile) so that they compile in parallel.
 #ifndef SFL_NS_GROUP
 #define SFL_NS_GROUP (-1)  // single translation unit: every depth
+#endif
+#ifndef SFL_FOLD_PART
+#define SFL_FOLD_PART (-1)  // both arithmetics in this translation unit
 #endif
 #define SFL_ENTRY_ARGS                                                                             \
     hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, SorParams prm, \
         int rows_per_chunk, int sweep, const HaloWait *wait, int *senders
-#define SFL_DEFINE_PART(N, P)                                                                      \
-    hipError_t launch_sor_fused_ns##N##_p##P(SFL_ENTRY_ARGS)                                       \
+#define SFL_DEFINE_PART(N, P, F)                                                                   \
+    hipError_t launch_sor_fused_ns##N##_p##P##_f##F(SFL_ENTRY_ARGS)                                \
     {                                                                                             \
-        return launch_ns<N>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);   \
+        return launch_ns<N, F != 0>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders); \
     }
 #if SFL_DX_PART == 0
-#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0)
+#define SFL_DEFINE_DX(N, F) SFL_DEFINE_PART(N, 0, F)
 #elif SFL_DX_PART == 1
-#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 1)
+#define SFL_DEFINE_DX(N, F) SFL_DEFINE_PART(N, 1, F)
 #else
-#define SFL_DEFINE_NS(N) SFL_DEFINE_PART(N, 0) SFL_DEFINE_PART(N, 1)
+#define SFL_DEFINE_DX(N, F) SFL_DEFINE_PART(N, 0, F) SFL_DEFINE_PART(N, 1, F)
+#endif
+#if SFL_FOLD_PART == 0
+#define SFL_DEFINE_NS(N) SFL_DEFINE_DX(N, 0)
+#elif SFL_FOLD_PART == 1
+#define SFL_DEFINE_NS(N) SFL_DEFINE_DX(N, 1)
+#else
+#define SFL_DEFINE_NS(N) SFL_DEFINE_DX(N, 0) SFL_DEFINE_DX(N, 1)
 #endif
 #define SFL_DECLARE_NS(N)                                                                         \
-    hipError_t launch_sor_fused_ns##N##_p0(SFL_ENTRY_ARGS);                                       \
-    hipError_t launch_sor_fused_ns##N##_p1(SFL_ENTRY_ARGS);
+    hipError_t launch_sor_fused_ns##N##_p0_f0(SFL_ENTRY_ARGS);                                    \
+    hipError_t launch_sor_fused_ns##N##_p1_f0(SFL_ENTRY_ARGS);                                    \
+    hipError_t launch_sor_fused_ns##N##_p0_f1(SFL_ENTRY_ARGS);                                    \
+    hipError_t launch_sor_fused_ns##N##_p1_f1(SFL_ENTRY_ARGS);
 SFL_DECLARE_NS(2) SFL_DECLARE_NS(4) SFL_DECLARE_NS(6) SFL_DECLARE_NS(8)
 SFL_DECLARE_NS(10) SFL_DECLARE_NS(12) SFL_DECLARE_NS(14) SFL_DECLARE_NS(16)
 #if SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1
@@ -513,14 +526,14 @@ SFL_DEFINE_NS(16)
     hipError_t launch_sor_chain_ns##N##_p0(SFL_CHAIN_ARGS);   \
     hipError_t launch_sor_chain_ns##N##_p1(SFL_CHAIN_ARGS);
 SFL_DECLARE_CHAIN(8) SFL_DECLARE_CHAIN(10) SFL_DECLARE_CHAIN(12) SFL_DECLARE_CHAIN(16)
-#if SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1
+#if (SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1) && SFL_FOLD_PART != 1
 SFL_DEFINE_CHAIN(8) SFL_DEFINE_CHAIN(10)
 #endif
-#if SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1
+#if (SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1) && SFL_FOLD_PART != 1
 SFL_DEFINE_CHAIN(12) SFL_DEFINE_CHAIN(16)
 #endif
 
-#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
+#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1 && SFL_FOLD_PART != 1
 bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps)
 {
     const uintptr_t all = reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(d);
@@ -552,7 +565,7 @@ hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d,
 }
 #endif
 
-#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1
+#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1 && SFL_FOLD_PART != 1
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d,
                             Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
@@ -565,8 +578,11 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
     const bool dx1 = prm.dx == 1.0f;
 #define SFL_CASE(N)                                                                                              \
     case N:                                                                                                      \
-        return dx1 ? launch_sor_fused_ns##N##_p0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders) \
-                   : launch_sor_fused_ns##N##_p1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        if (prm.fold)                                                                                            \
+            return dx1 ? launch_sor_fused_ns##N##_p0_f1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders) \
+                       : launch_sor_fused_ns##N##_p1_f1(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders); \
+        return dx1 ? launch_sor_fused_ns##N##_p0_f0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders) \
+                   : launch_sor_fused_ns##N##_p1_f0(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
     switch (nsweeps) {
         SFL_CASE(2) SFL_CASE(4) SFL_CASE(6) SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(14) SFL_CASE(16)
     }

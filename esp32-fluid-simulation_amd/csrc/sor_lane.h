@@ -145,10 +145,13 @@ struct WaveCommon {
 // for the launch, profiles/r04_experiments_without_gain.txt 3).
 // LD = cache policy of the p loads (VEC only): 0 plain; 16 = sc1, past the CU's L1 -- the chained launch (sor_chain_kernel), whose
 // tiles read rows that other CUs stored (written-through) while the launch is running.
-template <int NS, bool VEC, bool ZERO_IN, int ST = 0, int LD = 0>
+// FOLD = the interior relaxation's one product by -0.25f * omega (SFL_OPT_SOR_FOLD = 1; sor_stream_core.h relax); false: the
+// reference's two products, its bits on every input.
+template <int NS, bool VEC, bool ZERO_IN, int ST = 0, int LD = 0, bool FOLD = false>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
+    static constexpr bool kFoldQuarter = FOLD;
         // three rows in flight ahead of the pipeline: six cost 12 more VGPRs (and, with the rhs read-ahead, spills
     // at NS = 16) without being faster (profiles/r02_rhs_read_ahead.txt)
     static constexpr int kTileCols = 128, kColAlign = 2, kCells = 2, kPrefetch = 3, kTurnRows = SFL_PRIO_ROWS;

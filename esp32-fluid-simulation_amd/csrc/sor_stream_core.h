@@ -82,6 +82,7 @@ struct Consts {
 };
 
 // B::kPrefetch = rows in flight ahead of the pipeline (must divide 6, hence every RING)
+// B::kFoldQuarter = the interior relaxation multiplies once by -0.25f * omega instead of by -0.25f and by omega (relax)
 // E[k] / O[k] hold the two colours of the row whose index is k modulo RING -- the NEWEST version
 // of that row computed so far: a relaxation overwrites its own input (the previous version's last
 // reader is the relaxation that replaces it, see iterate()), exactly as SOR does in memory.
@@ -103,14 +104,18 @@ SFL_HD typename B::V relax(const B &bk, const Consts<B> &c, typename B::V own, t
     using V = typename B::V;
     const V rhs = d;   // fl(dx * d), formed when the row entered the ring (iterate)
     if (!EDGE) {
-        // poisson.cpp:107-111 asks for fl(omega * fl(-0.25f * t)), t = dx * d - sum.  Scaling by -0.25 is exact unless the
-        // product underflows inexactly, and so is -0.25f * omega: fl(omega * (-0.25f * t)) == fl((-0.25f * omega) * t), ONE
-        // rounded multiplication instead of two -- 7 vector instructions per relaxation instead of 8, bit for bit the same
-        // result whenever t is a multiple of 2^-147, i.e. unless an operand (dx * d or a neighbour's p) is a nonzero number
-        // below 2^-124 = 4.7e-38.  (There the reference rounds -0.25f * t to a denormal first and the two products can differ
-        // by one unit of 2^-149: tests/test_gpu_parity.py test_folded_quarter_omega_at_the_edges_of_float, DESIGN 3.  An omega
-        // whose own quarter would underflow never gets here: host::sor_fold_is_exact sends that solve to the one-pass kernel.)
         const V sum = ((w + e) + s) + n;
+        // poisson.cpp:107-111: p_gs = -0.25f * (dx * d - sum); p = (1 - omega) * p + omega * p_gs -- every product rounded on its
+        // own, 8 vector instructions, the reference's bits on EVERY input.  This is what the library runs unless asked otherwise.
+        if (!B::kFoldQuarter) return c.one_minus_omega * own + c.omega * (bk.splat(-0.25f) * (rhs - sum));
+        // SFL_OPT_SOR_FOLD = 1 (opt-in): fl(omega * fl(-0.25f * t)), t = dx * d - sum, as ONE rounded product fl((-0.25f * omega) * t) --
+        // 7 instructions, the relaxation's dependency chain one shorter (+2.4 .. 3 % on 8192^2).  Scaling by -0.25 is exact unless
+        // the product underflows inexactly, so the two are the same bits whenever t is a multiple of 2^-147, i.e. unless an operand
+        // (dx * d or a neighbour's p) is a nonzero number below 2^-124 = 4.7e-38.  That is no edge of float: the front of a solution
+        // that decays into a quiescent region (zero right-hand side -- the sketch's own start, ino:199,264-276) passes through that
+        // range from ~63 iterations on, and there the reference rounds -0.25f * t to a denormal first and the two products can differ
+        // by one unit of 2^-149, which later passes carry along (tests/test_gpu_parity.py test_quiescent_*; an omega whose
+        // own quarter would underflow is solved unfolded whatever the option says, sor_executor.cpp).
         return c.one_minus_omega * own + c.neg_quarter_omega * (rhs - sum);
     }
     const V z = rf.full ? ec.z_full : bk.splat(0.0f);

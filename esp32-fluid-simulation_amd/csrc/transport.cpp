@@ -467,13 +467,13 @@ int sfl_comm_unique_id(void *id_out, size_t id_bytes)
 
 // Everything that must be identical on all ranks of a communicator for their programs to match: the domain,
 // the group size and every option a plan or an exchange depends on.
-constexpr int kOptionBlockInts = 16;
+constexpr int kOptionBlockInts = 17;
 static void option_block(const sfl_context *c, int *b)
 {
     const int v[kOptionBlockInts] = {SFL_ABI_VERSION, c->dim_x, c->gdim_y, c->nranks, c->opt_sor_kernel, c->opt_sor_fuse,
                                      c->opt_sor_halo, c->opt_sor_overlap, c->opt_advect_halo, c->opt_fuse_projection,
                                      c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, c->opt_sor_arrival,
-                                     c->opt_sor_chain, c->streams_concurrent};
+                                     c->opt_sor_chain, c->opt_sor_fold, c->streams_concurrent};   // (streams_concurrent LAST: sfl_comm_check_options)
     memcpy(b, v, sizeof v);
 }
 
@@ -648,6 +648,7 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_sor_arrival = z->opt_sor_arrival;
         c->opt_sor_chain = z->opt_sor_chain;
         c->opt_halo_timeout_ms = z->opt_halo_timeout_ms;
+        c->opt_sor_fold = z->opt_sor_fold;
     }
     for (int r = 0; r < n; ++r) {  // one stream orders the whole group
         sfl_context *c = ctxs[r];

@@ -270,10 +270,10 @@ class HostPath:
     kind = "hip"
 
     def __init__(self, device: int = 0, sor_kernel: int = 0, sor_fuse: int = 0, sor_rows: int = 0,
-                 sor_lane_cells: int = 0):
+                 sor_lane_cells: int = 0, sor_fold: int = 0):
         self._lib = capi.lib()
         self.device, self.sor_kernel, self.sor_fuse, self.sor_rows = device, sor_kernel, sor_fuse, sor_rows
-        self.sor_lane_cells = sor_lane_cells
+        self.sor_lane_cells, self.sor_fold = sor_lane_cells, sor_fold
 
     @staticmethod
     def _dims(a):
@@ -289,6 +289,8 @@ class HostPath:
             s.set_option(capi.OPT_SOR_ROWS, self.sor_rows)
         if self.sor_lane_cells:
             s.set_option(capi.OPT_SOR_LANE_CELLS, self.sor_lane_cells)
+        if self.sor_fold:
+            s.set_option(capi.OPT_SOR_FOLD, self.sor_fold)
         return s
 
     def advect_vec2f(self, p, vel, dt, no_slip=True):

@@ -58,12 +58,7 @@ extern "C" {
 /* ---- tunables (sfl_set_option / sfl_get_option) ------------------------------------------ */
 #define SFL_OPT_SOR_KERNEL 0      /* 0 = auto, 1 = one launch per colour pass (baseline kernel),
                                      2 = fused multi-pass streaming kernel.  Both give the reference's
-                                     bits; kernel 2 multiplies once by -0.25f * omega where poisson.cpp:109-111
-                                     multiplies twice, which is the same rounding unless an operand (dx * d or
-                                     a neighbour's p) is a nonzero number below 2^-124 = 4.7e-38 -- fields that
-                                     live down there agree within units of 2^-149 instead;
-                                     kernel 1 has no such condition, and an omega whose quarter underflows
-                                     is solved by it whatever this option says                    */
+                                     bits on every input (unless SFL_OPT_SOR_FOLD is set)          */
 #define SFL_OPT_SOR_FUSE 1        /* colour passes fused per launch by kernel 2: even, 2..16, or
                                      0 = auto (16 on slabs of >= 12 M cells, 10 from 3 M, else 8) */
 #define SFL_OPT_ADVECT_HALO 2     /* slabs: rows of the advected field exchanged per side.  0 (default) =
@@ -171,6 +166,21 @@ extern "C" {
                                      solve (SFL_OPT_SOR_HALO = 0) is chosen from it: deeper halos = fewer exchanges, more rows
                                      relaxed redundantly                                                             */
 #define SFL_OPT_LAST_HALO 21         /* READ ONLY: halo depth (rows of p per superstep) of the last solve's plan on this slab  */
+#define SFL_OPT_SOR_FOLD 22          /* kernel 2's interior relaxation, poisson.cpp:107-111.  0 (default) = as the reference writes it,
+                                     (1 - omega) * p + omega * (-0.25f * t), t = dx * d - sum: every product rounded on its own, the
+                                     reference's bits on EVERY input.  1 = (1 - omega) * p + (-0.25f * omega) * t: one product less (7
+                                     instead of 8 vector instructions per cell and pass, measured +2.4 .. 3 % cell-iters/s at 8192^2).
+                                     The same bits wherever every operand of t (dx * d and the four neighbours' p) is zero or at least
+                                     2^-124 = 4.7e-38 in magnitude -- dense fields.  Where one is a nonzero number below that -- the
+                                     decaying front of a sparsely forced solution in a quiescent region reaches that range after ~63
+                                     iterations: the sketch's own scenario -- the reference rounds -0.25f * t to a denormal first and
+                                     the folded product can differ by one unit of 2^-149.  After ONE solve only cells of that front
+                                     differ (absolute differences <= ~1e-40).  Over repeated sim steps the difference climbs the scales
+                                     of a field that holds every magnitude down to the denormals, and pressure and velocity end up with
+                                     ordinary rounding noise against the reference (units in the last place of each value; 1e-8 of the
+                                     field's maximum after three steps at 80 iterations) -- inside north_star's 1e-5, but not the
+                                     reference's bits.  Opt in only if that is acceptable; the boundary cells keep both products
+                                     either way (tests/test_gpu_parity.py test_quiescent_*)                        */
 
 typedef struct sfl_context sfl_context;
 

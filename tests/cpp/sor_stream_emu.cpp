@@ -40,10 +40,12 @@ EMU_BINOP(-)
 EMU_BINOP(*)
 #undef EMU_BINOP
 
-struct EmuBackend {
+template <bool FOLD>
+struct EmuBackendT {
     using V = V64;
     using M = M64;
     static constexpr int kPrefetch = 3;
+    static constexpr bool kFoldQuarter = FOLD;   // SFL_OPT_SOR_FOLD (sor_stream_core.h relax)
 
     const float *p_in;
     const float *d;
@@ -160,6 +162,7 @@ struct EmuBackend {
     void next_turn() {}
 };
 
+template <class EmuBackend>
 sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
 {
     sfl::sor::EdgeCell<EmuBackend> ec;
@@ -175,12 +178,13 @@ sfl::sor::EdgeCell<EmuBackend> edge_cells(int x0, int which, int dim_x)
     return ec;
 }
 
-template <int NS>
-int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
+template <int NS, bool FOLD>
+int run_tiles_as(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
                int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,
                bool vec2, bool poison, bool force_edge, bool balance, int flip, int *flipped_tiles)
 {
     using namespace sfl::sor;
+    using EmuBackend = EmuBackendT<FOLD>;
     const Tiling t = make_tiling(NS, 128, 2, dim_x, gdim_y, g_begin, g_end, rows_per_chunk,
                                  balance ? kEdgeRowCost16 : 0, flip);
     int stray = 0;
@@ -211,7 +215,7 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
             const bool edge = force_edge || tile_touches_boundary(t, rect, gdim_y);
             const bool flipped = !edge && tile_may_flip(t, rect);
             const bool dx1 = dx == 1.0f;
-            const auto eca = edge_cells(bk.x0, 0, dim_x), ecb = edge_cells(bk.x0, 1, dim_x);
+            const auto eca = edge_cells<EmuBackend>(bk.x0, 0, dim_x), ecb = edge_cells<EmuBackend>(bk.x0, 1, dim_x);
             const bool zero_in = p_in == nullptr;
 #define EMU_RUN(EDGE, DX1, ZERO) stream_tile<EmuBackend, NS, EDGE, DX1, ZERO>(bk, c, eca, ecb, r0, r1)
             if (edge) {
@@ -236,21 +240,31 @@ int run_tiles(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 
 }  // namespace
 
-// One non-template entry per fuse depth; the depths are spread over several objects
-// (-DEMU_NS_GROUP=0..3, see Makefile) because a single translation unit takes four minutes.
+// One non-template entry per fuse depth and arithmetic (exact / folded quarter); the depths and arithmetics are spread over
+// several objects (-DEMU_NS_GROUP=0..3 -DEMU_FOLD_PART=0/1, see Makefile) because a single translation unit takes eight minutes.
 #ifndef EMU_NS_GROUP
 #define EMU_NS_GROUP (-1)  // everything in one translation unit
+#endif
+#ifndef EMU_FOLD_PART
+#define EMU_FOLD_PART (-1)  // both arithmetics in this translation unit
 #endif
 #define EMU_ARGS float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0, \
                  int lrows, int g_begin, int g_end, float dx, float omega, int rows_per_chunk,      \
                  bool vec2, bool poison, bool force_edge, bool balance, int flip, int *flipped_tiles
-#define EMU_DECLARE(N) int emu_run_ns##N(EMU_ARGS);
-#define EMU_DEFINE(N)                                                                             \
-    int emu_run_ns##N(EMU_ARGS)                                                                   \
+#define EMU_DECLARE(N) int emu_run_ns##N##_f0(EMU_ARGS); int emu_run_ns##N##_f1(EMU_ARGS);
+#define EMU_DEFINE_F(N, F)                                                                        \
+    int emu_run_ns##N##_f##F(EMU_ARGS)                                                            \
     {                                                                                             \
-        return run_tiles<N>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
-                            rows_per_chunk, vec2, poison, force_edge, balance, flip, flipped_tiles); \
+        return run_tiles_as<N, F != 0>(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, omega, \
+                                       rows_per_chunk, vec2, poison, force_edge, balance, flip, flipped_tiles); \
     }
+#if EMU_FOLD_PART == 0
+#define EMU_DEFINE(N) EMU_DEFINE_F(N, 0)
+#elif EMU_FOLD_PART == 1
+#define EMU_DEFINE(N) EMU_DEFINE_F(N, 1)
+#else
+#define EMU_DEFINE(N) EMU_DEFINE_F(N, 0) EMU_DEFINE_F(N, 1)
+#endif
 EMU_DECLARE(2) EMU_DECLARE(4) EMU_DECLARE(6) EMU_DECLARE(8)
 EMU_DECLARE(10) EMU_DECLARE(12) EMU_DECLARE(14) EMU_DECLARE(16)
 #if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
@@ -266,11 +280,12 @@ EMU_DEFINE(14)
 EMU_DEFINE(16)
 #endif
 
-#if EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1
+#if (EMU_NS_GROUP == 0 || EMU_NS_GROUP == -1) && EMU_FOLD_PART != 1
 // flags: bit0 = emulate the VEC2 access variant, bit1 = NaN-poison pipeline state,
 //        bit2 = force the EDGE path for every tile, bit3 = uniform tiling (no short boundary tiles),
 //        bit4 = every second chunk of an inner strip is streamed top-down (the product's default): the odd chunks,
 //        bit5 = ... the even chunks instead (the product's odd launches of a solve on big slabs)
+//        bit6 = SFL_OPT_SOR_FOLD: the interior relaxation's single product by -0.25f * omega (default: the reference's two products)
 // returns the number of tiles streamed top-down (>= 0), or a negative error
 extern "C" __attribute__((visibility("default"))) int
 emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gdim_y, int grow0,
@@ -279,11 +294,12 @@ emu_sor_fused(float *p_out, const float *p_in, const float *d, int dim_x, int gd
 {
     const bool vec2 = flags & 1, poison = flags & 2, force_edge = flags & 4, balance = !(flags & 8);
     const int flip = (flags & 32) ? 2 : (flags & 16) ? 1 : 0;
+    const bool fold = flags & 64;
     int flipped_tiles = 0;
     if (vec2 && (dim_x & 1)) return -1;
 #define EMU_CASE(N)                                                                          \
     case N:                                                                                  \
-        return emu_run_ns##N(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
+        return (fold ? emu_run_ns##N##_f1 : emu_run_ns##N##_f0)(p_out, p_in, d, dim_x, gdim_y, grow0, lrows, g_begin, g_end, dx, \
                              omega, rows_per_chunk, vec2, poison, force_edge, balance, flip, &flipped_tiles) ? -3 : flipped_tiles;
     switch (ns) {
         EMU_CASE(2) EMU_CASE(4) EMU_CASE(6) EMU_CASE(8) EMU_CASE(10) EMU_CASE(12) EMU_CASE(14)

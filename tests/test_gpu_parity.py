@@ -153,29 +153,134 @@ def test_signed_zero_and_zero_rhs(sfl, oracle):
 
 
 def test_folded_quarter_omega_at_the_edges_of_float(sfl, oracle):
-    """The fused kernel's interior relaxation multiplies once by -0.25f * omega where poisson.cpp:109-111 multiplies by -0.25f and
-    then by omega (csrc/sor_stream_core.h relax).  The same bits unless a quarter underflows INEXACTLY: an omega below 2^-124 goes
-    to the one-pass kernel (exact); a residual t = dx * d - sum has bits below 2^-147 only if one of its operands is a nonzero
-    number below 2^-124 (4.7e-38) -- then -0.25f * t is rounded once instead of twice, one unit of 2^-149 apart, which later
-    passes amplify like any perturbation.  Fields that live at the very bottom of the float range agree within north_star's
-    tolerance (1e-5 of the field's maximum) instead of bit for bit; everything above stays bit-exact."""
+    """poisson.cpp:109-111 multiplies by -0.25f and then by omega; so does the fused kernel (csrc/sor_stream_core.h relax), and
+    is therefore bit-exact down to the last denormal.  SFL_OPT_SOR_FOLD = 1 multiplies once, by -0.25f * omega: the same bits
+    unless a quarter underflows INEXACTLY -- an omega below 2^-124 is solved unfolded whatever the option says; a residual
+    t = dx * d - sum has bits below 2^-147 only if one of its operands is a nonzero number below 2^-124 (4.7e-38), then -0.25f * t
+    is rounded once instead of twice, one unit of 2^-149 apart, which later passes amplify like any perturbation.  Folded, fields
+    that live at the very bottom of the float range agree within north_star's tolerance (1e-5 of the field's maximum) instead
+    of bit for bit; everything above stays bit-exact."""
     _, _, d = random_fields(300, 150, 21)
-    for omega in (np.float32(1e-39), np.float32(3e-38), np.float32(2.0 ** -124), np.float32(0.0), np.float32(-1.5)):
-        hp = sfl.HostPath(sor_kernel=2, sor_fuse=8)
-        assert_bit_equal(hp.poisson_solve(d, 1.0, 5, omega), oracle.poisson_solve(d, 1.0, 5, omega), f"omega {omega}")
-    for exp in (-60, -100):   # (no operand below 2^-124: a Gaussian sample is not 2^-24 small)
-        small = (d * np.float32(2.0 ** exp)).astype(np.float32)
-        assert_bit_equal(sfl.HostPath(sor_kernel=2, sor_fuse=8).poisson_solve(small, 1.0, 6, OMEGA),
-                         oracle.poisson_solve(small, 1.0, 6, OMEGA), f"right-hand side scaled by 2^{exp}")
+    for fold in (0, 1):
+        for omega in (np.float32(1e-39), np.float32(3e-38), np.float32(2.0 ** -124), np.float32(0.0), np.float32(-1.5)):
+            hp = sfl.HostPath(sor_kernel=2, sor_fuse=8, sor_fold=fold)
+            assert_bit_equal(hp.poisson_solve(d, 1.0, 5, omega), oracle.poisson_solve(d, 1.0, 5, omega), f"omega {omega} fold {fold}")
+        for exp in (-60, -100):   # (no operand below 2^-124: a Gaussian sample is not 2^-24 small)
+            small = (d * np.float32(2.0 ** exp)).astype(np.float32)
+            assert_bit_equal(sfl.HostPath(sor_kernel=2, sor_fuse=8, sor_fold=fold).poisson_solve(small, 1.0, 6, OMEGA),
+                             oracle.poisson_solve(small, 1.0, 6, OMEGA), f"right-hand side scaled by 2^{exp}, fold {fold}")
     for exp in (-118, -122, -126, -140):
         tiny = (d * np.float32(2.0 ** exp)).astype(np.float32)
-        got = sfl.HostPath(sor_kernel=2, sor_fuse=8).poisson_solve(tiny, 1.0, 6, OMEGA).astype(np.float64)
         want = oracle.poisson_solve(tiny, 1.0, 6, OMEGA)
+        # the default arithmetic, fused and one pass per launch: the reference's bits
+        assert_bit_equal(sfl.HostPath(sor_kernel=2, sor_fuse=8).poisson_solve(tiny, 1.0, 6, OMEGA), want, f"fused kernel, 2^{exp}")
+        assert_bit_equal(sfl.HostPath(sor_kernel=2, sor_fuse=16).poisson_solve(tiny, 1.0, 6, OMEGA), want, f"fused kernel, 2^{exp}")
+        assert_bit_equal(sfl.HostPath(sor_kernel=1).poisson_solve(tiny, 1.0, 6, OMEGA), want, f"one-pass kernel, 2^{exp}")
+        got = sfl.HostPath(sor_kernel=2, sor_fuse=8, sor_fold=1).poisson_solve(tiny, 1.0, 6, OMEGA).astype(np.float64)
         apart = np.max(np.abs(got - want.astype(np.float64)))
         # 1e-5 relative (north_star); where the whole field is denormal a unit of 2^-149 is already more than that: a few units
         assert apart <= max(1e-5 * np.max(np.abs(want)), 64 * 2.0 ** -149), f"2^{exp}: {apart / 2.0 ** -149} units of 2^-149 apart"
-        # ... and the one-pass kernel, which multiplies twice, needs no such allowance
-        assert_bit_equal(sfl.HostPath(sor_kernel=1).poisson_solve(tiny, 1.0, 6, OMEGA), want, f"one-pass kernel, 2^{exp}")
+
+
+# ---- the input class the reference's own demo produces (VERDICT r05 item 1): a quiescent field, sparse forcing, BASELINE iteration counts --
+def touch_dipoles(dim_x, dim_y, amplitude, touches):
+    """calculate_divergence (finitediff.cpp:29-30) of a zero velocity field (ino:199) after single-cell force writes (ino:264-269)."""
+    d = np.zeros((dim_y, dim_x), np.float32)
+    for fx, fy in touches:
+        i, j = int(dim_x * fx), int(dim_y * fy)
+        d[j, i - 1] += np.float32(0.5 * amplitude)
+        d[j, i + 1] -= np.float32(0.5 * amplitude)
+        d[j - 1, i] += np.float32(0.25 * amplitude)
+        d[j + 1, i] -= np.float32(0.25 * amplitude)
+    return d
+
+
+def differing(a, b):
+    return np.ascontiguousarray(a).view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)
+
+
+TINY = 2.0 ** -124
+_SPARSE_HEADLINE = {}
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+def test_quiescent_sparse_right_hand_side_at_the_headline_size(sfl, oracle, fold):
+    """poisson_solve (poisson.cpp:114-125) at BASELINE configuration 3's size and iteration count, 8192^2 x 80, on the right-hand
+    side the sketch's own start produces: zero (ino:199) but for a few touch dipoles (ino:264-276).  SOR at omega = 1.96 carries
+    a point source ~0.49 per cell and pass, so the solution's front -- 160 cells out after 80 iterations -- decays through the
+    denormals into cells that are still exactly zero.  Default arithmetic: every one of the 67 M cells has the reference's bits.
+    SFL_OPT_SOR_FOLD = 1: only cells of that front differ, by denormal-sized amounts (the bound include/sfl.h states)."""
+    dim, iters = 8192, 80
+    d = touch_dipoles(dim, dim, 20.0, [(0.5, 0.5), (0.12, 0.8), (0.97, 0.03), (0.6, 0.31)])
+    if "want" not in _SPARSE_HEADLINE:   # (one oracle solve for both arithmetics: ~5 s of a host core)
+        _SPARSE_HEADLINE["want"] = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    want = _SPARSE_HEADLINE["want"]
+    front = (want != 0) & (np.abs(want) < TINY)
+    assert front.sum() > 500 and (want == 0).mean() > 0.9, "the scenario must have a denormal front and a quiescent region"
+    with sfl.Solver(dim, dim) as s:
+        s.set_option(sfl.capi.OPT_SOR_FOLD, fold)
+        s.upload(sfl.capi.FIELD_DIVERGENCE, d)
+        s.poisson_solve(1.0, iters, OMEGA)
+        s.synchronize()
+        assert s.last_solve_info()["fuse"] == 16
+        got = s.download(sfl.capi.FIELD_PRESSURE)
+    if not fold:
+        assert_bit_equal(got, want, "8192^2 x 80 on a sparse right-hand side")
+        return
+    diff = differing(got, want)
+    assert diff.any(), "the folded product is expected to differ from the reference on this input (else: drop the option's caveat)"
+    assert np.abs(want[diff]).max() < 2.0 ** -100, "only cells of the decaying front may differ"
+    assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1e-38
+
+
+@pytest.mark.parametrize("fold", [0, 1])
+@pytest.mark.parametrize("nranks", [1, 4])
+def test_quiescent_field_with_drags_over_whole_sim_steps(sfl, oracle, nranks, fold):
+    """The sketch's scenario end to end (ino:199, 249-289): velocity zero, a handful of drag messages (sfl_queue_drags), then
+    sim steps at 80 SOR iterations on 1536 x 1024 -- three steps, so that the projected velocity of one step, which carries the
+    pressure front's denormals over most of the domain, is advected, differenced and solved for again in the next.  Whole domain
+    (sfl_step_n: seam kernels) and four virtual ranks.  Default arithmetic: velocity, divergence, pressure and dye bit for bit.
+    SFL_OPT_SOR_FOLD = 1 is NOT the reference's bits here, and not only in the denormal front: a field that holds every magnitude
+    between 2^-149 and 1 hands a one-unit difference at the bottom up the scales (a difference of 2^-149 flips the rounding of a
+    value 64 times larger once in 64 relaxations, and so on), so that after three steps pressure and velocity differ from the
+    reference by ordinary rounding noise -- measured 7.5e-9 absolute on a field of maximum 0.86, one to a few units in the last
+    place of the cells concerned (profiles/r06_numerics.txt).  The bound asserted: 1e-5 of each field's maximum (north_star's
+    tolerance read against the field's scale); the dye within one raw unit of UQ32."""
+    dim_x, dim_y, iters, steps = 1536, 1024, 80, 3
+    _, c, _ = random_fields(dim_x, dim_y, 77, 0.0)
+    v = np.zeros((dim_y, dim_x, 2), np.float32)
+    drags = [(512, 700, 35.0, -20.0), (513, 700, 30.0, -25.0), (100, 90, -60.0, 12.0), (900, 1400, 8.0, 90.0), (1023, 1535, 5.0, 5.0)]
+    forces = ([(y, x) for x, y, _, _ in drags], [(vy, vx) for _, _, vx, vy in drags])
+    vo, co = v, c
+    for k in range(steps):
+        vo, do, po, co = oracle_step(oracle, vo, co, iters, forces if k == 0 else None)
+    assert ((po != 0) & (np.abs(po) < TINY)).sum() > 100, "the scenario must reach the denormal range"
+    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
+    try:
+        if nranks > 1:
+            sfl.Solver.link_group(slabs)
+        for s in slabs:
+            s.set_option(sfl.capi.OPT_SOR_FOLD, fold)
+            s.upload(sfl.capi.FIELD_VELOCITY, v[s.row_begin:s.row_end])
+            s.upload(sfl.capi.FIELD_COLOR, c[s.row_begin:s.row_end])
+        slabs[0].queue_drags(drags)
+        slabs[0].step_n(steps, DT, 1.0, iters, OMEGA)
+        slabs[0].synchronize()
+        cat = lambda f: np.concatenate([s.download(f) for s in slabs], axis=0)
+        gv, gd, gp, gc = (cat(f) for f in (sfl.capi.FIELD_VELOCITY, sfl.capi.FIELD_DIVERGENCE, sfl.capi.FIELD_PRESSURE,
+                                           sfl.capi.FIELD_COLOR))
+    finally:
+        for s in slabs:
+            s.close()
+    if not fold:
+        for name, a, b in zip(("velocity", "divergence", "pressure", "dye"), (gv, gd, gp, gc), (vo, do, po, co)):
+            assert_bit_equal(a, b, f"{name}, {nranks} rank(s)")
+        return
+    # (the dye: the same bits after these three steps, 3 of 1.5 M cells one raw unit apart after a fourth -- tests/fold_numerics_probe.py)
+    assert np.abs(gc.astype(np.int64) - co.astype(np.int64)).max() <= 1, "dye"
+    assert differing(gp, po).any(), "the folded product is expected to differ from the reference on this input"
+    for name, a, b in zip(("velocity", "divergence", "pressure"), (gv, gd, gp), (vo, do, po)):
+        assert np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= 1e-5 * np.abs(b).max(), name
 
 
 def test_iters_zero_gives_zero_pressure(hip):

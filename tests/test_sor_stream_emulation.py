@@ -24,7 +24,7 @@ def emu():
         so = os.path.join(d, "libsor_stream_emu.so")
         with open(os.path.join(d, ".emu_build.lock"), "w") as lock:   # (pytest -n: one worker builds, the others wait)
             fcntl.flock(lock, fcntl.LOCK_EX)
-            subprocess.run(["make", "-C", d, "-j4", so], check=True, stdout=subprocess.DEVNULL)
+            subprocess.run(["make", "-C", d, "-j8", so], check=True, stdout=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.emu_sor_fused.argtypes = [_F, _F, _F] + [C.c_int] * 7 + [C.c_float, C.c_float, C.c_int, C.c_int]
     lib.emu_sor_fused.restype = C.c_int
@@ -37,13 +37,13 @@ def emu():
     lib.emu_tile_order.restype = C.c_int
 
     def run(p_in, d, ns, *, dx=1.0, omega=OMEGA, rows=32, vec2=False, force_edge=False,
-            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, flip=True):
+            gdim_y=None, grow0=0, g_begin=0, g_end=None, out=None, uniform=False, flip=True, fold=False):
         lrows, dim_x = d.shape
         gdim_y = lrows if gdim_y is None else gdim_y
         g_end = gdim_y if g_end is None else g_end
         out = np.full_like(d, np.nan) if out is None else out
         fp = lambda a: None if a is None else a.ctypes.data_as(_F)
-        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (32 if flip == 2 else 16 if flip else 0)
+        flags = (1 if vec2 else 0) | 2 | (4 if force_edge else 0) | (8 if uniform else 0) | (32 if flip == 2 else 16 if flip else 0) | (64 if fold else 0)
         rc = lib.emu_sor_fused(fp(out), fp(p_in), fp(d), dim_x, gdim_y, grow0, lrows, g_begin, g_end,
                                ns, dx, omega, rows, flags)
         assert rc >= 0
@@ -216,3 +216,68 @@ def test_alternating_stream_direction(emu, oracle, ns, dim_x, dim_y, rows):
     assert_bit_equal(emu(p0, d, ns, rows=rows, flip=2), oracle.sor_iterate(p0, d, 1.0, ns // 2, OMEGA), "even chunks flipped")
     if dim_x > 300:
         assert emu.flipped_tiles > 0
+
+
+# ---- the input class the reference's own demo produces: a quiescent field with sparse forcing ----------
+def sparse_rhs(dim_x, dim_y, amplitude, touches=((0.5, 0.5),)):
+    """Divergence of a zero velocity field (ino:199) after a few touch-like single-cell force writes (ino:264-269): zero except for
+    the +-dipoles calculate_divergence (finitediff.cpp:29-30) makes of each written cell."""
+    d = np.zeros((dim_y, dim_x), np.float32)
+    for fx, fy in touches:
+        i, j = int(dim_x * fx), int(dim_y * fy)
+        d[j, i - 1] += np.float32(0.5 * amplitude)
+        d[j, i + 1] -= np.float32(0.5 * amplitude)
+        d[j - 1, i] += np.float32(0.25 * amplitude)
+        d[j + 1, i] -= np.float32(0.25 * amplitude)
+    return d
+
+
+def solve_by_launches(emu, d, iters, ns, **kw):
+    """poisson_solve as the executor issues it: launches of ns passes, the first from zero, even and odd launches flipping the
+    other chunks (sor_executor.cpp / sor_fused.hip launch_variant)."""
+    p, left, k = None, 2 * iters, 0
+    while left > 0:
+        n = min(ns, left)
+        p = emu(p, d, n, rows=48, flip=1 + (k & 1), **kw)
+        left -= n
+        k += 1
+    return p
+
+
+TINY = np.float32(2.0 ** -124)   # below this a nonzero operand makes -0.25f * t round (sor_stream_core.h relax)
+
+
+@pytest.mark.parametrize("dim,iters,amplitude", [(384, 80, 1.0), (384, 80, 30.0), (512, 120, 5.0)])
+def test_quiescent_field_with_sparse_forcing_is_bit_exact(emu, oracle, dim, iters, amplitude):
+    """A zero field with one touch-like dipole in the right-hand side, at BASELINE iteration counts (poisson.cpp:114-125 on the
+    state ino:199,264-276 produce): SOR at omega = 1.96 spreads the source by ~0.49 per cell and pass, so from ~63 iterations on
+    the solution's front decays THROUGH the denormal range on its way into the region that is still exactly zero.  The library's
+    default arithmetic (two products, as poisson.cpp:109-111 writes them) gives the reference's bits there too."""
+    d = sparse_rhs(dim, dim, amplitude)
+    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
+    tiny = (want != 0) & (np.abs(want) < TINY)
+    assert tiny.sum() > 50, "the scenario must reach the range where the products differ"
+    assert (want == 0).sum() > 1000, "... and keep a quiescent region beyond the front"
+    assert_bit_equal(solve_by_launches(emu, d, iters, 16), want, "exact arithmetic, fuse 16")
+    assert_bit_equal(solve_by_launches(emu, d, iters, 10), want, "exact arithmetic, fuse 10")
+
+
+def test_folded_quarter_omega_differs_only_in_the_decaying_front(emu, oracle):
+    """SFL_OPT_SOR_FOLD = 1 (opt-in): (1 - omega) * p + (-0.25f * omega) * t.  On the sparse scenario it is NOT the reference's bits --
+    this test fails if the folded arithmetic is made the default without anybody noticing -- and what it costs is bounded as the
+    documentation says (include/sfl.h SFL_OPT_SOR_FOLD): only cells of the front differ, by absolute amounts that are denormal-sized;
+    on a dense right-hand side the two arithmetics are the same bits."""
+    d = sparse_rhs(384, 384, 1.0)
+    want = oracle.poisson_solve(d, 1.0, 80, OMEGA)
+    got = solve_by_launches(emu, d, 80, 16, fold=True)
+    differs = bits_differ(got, want)
+    assert differs.any(), "the folded product should differ from the reference on this input"
+    assert np.abs(want[differs]).max() < 2.0 ** -110, "only the decaying front may differ"
+    assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() < 1e-40
+    dense = sparse_rhs(384, 384, 1.0) + np.float32(1e-3) * np.random.default_rng(5).standard_normal((384, 384)).astype(np.float32)
+    assert_bit_equal(solve_by_launches(emu, dense, 80, 16, fold=True), oracle.poisson_solve(dense, 1.0, 80, OMEGA),
+                     "folded arithmetic on a dense right-hand side")
+
+
+def bits_differ(a, b):
+    return np.ascontiguousarray(a).view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)

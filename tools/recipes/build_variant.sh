@@ -29,10 +29,10 @@ for s in $sources; do
   file=${s%%:*}
   if [ $file = sor_fused.hip ]; then
     groups=${s#*:}; [ "$groups" = "$s" ] && groups="2,5"
-    for g in ${groups//,/ }; do for p in 0 1; do
-      hipcc $F $flags -DSFL_NS_GROUP=$g -DSFL_DX_PART=$p -c $SRC/sor_fused.hip -o $OUT/sor_fused_g${g}_p$p.o &
-      replaced="$replaced sor_fused_g${g}_p$p.o"
-    done; done
+    for g in ${groups//,/ }; do for p in 0 1; do for f in 0 1; do
+      hipcc $F $flags -DSFL_NS_GROUP=$g -DSFL_DX_PART=$p -DSFL_FOLD_PART=$f -c $SRC/sor_fused.hip -o $OUT/sor_fused_g${g}_p${p}_f$f.o &
+      replaced="$replaced sor_fused_g${g}_p${p}_f$f.o"
+    done; done; done
   else
     b=$(basename ${file%.*}).o
     case $file in *.cpp) x="-x hip";; *) x="";; esac
