@@ -200,7 +200,7 @@ def kernel_source_hash():
     another version of them are not this kernel's."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("sor_fused.hip", "sor_lane.h", "sor_chain.h", "sor_stream_core.h"):
+    for name in ("sor_fused.hip", "sor_lane.h", "sor_stream_core.h"):
         with open(os.path.join(ROOT, PKG, "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -315,17 +315,15 @@ def parse_args(argv=None):
     ap.add_argument("--wire-us", type=int, default=0,
                     help="--emulate-rank: hold every emulated halo message back by this many microseconds on the "
                          "exchange stream (SFL_OPT_EMULATE_WIRE_US): how much xGMI latency does the schedule hide?")
-    ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_SOR_OVERLAP = 0 (A/B)")
-    ap.add_argument("--chain", type=int, default=None, choices=(-1, 0, 1),
-                    help="SFL_OPT_SOR_CHAIN: 1 = the launches of a solve as chained launches (waves go from one superstep to the "
-                         "next, tiles wait for the tiles around them), 0 = one launch per superstep, -1 = automatic (thin slabs "
-                         "with a transport); default: the library's (0)")
+    ap.add_argument("--no-overlap", action="store_true", help="SFL_OPT_EXCHANGE_SCHEDULE = 1: every halo exchange in line (A/B)")
     ap.add_argument("--arrival-by-event", action="store_true",
-                    help="SFL_OPT_SOR_ARRIVAL = 0: early halo exchanges behind cross-stream events (round 3's scheme) instead of "
-                         "in-time exchanges counted on the device (A/B)")
+                    help="SFL_OPT_EXCHANGE_SCHEDULE = 2: early halo exchanges behind cross-stream events (round 3's scheme; the "
+                         "library's own choice on RCCL ranks whose peers are other processes)")
     ap.add_argument("--arrival-in-time", action="store_true",
-                    help="SFL_OPT_SOR_ARRIVAL = 1: exchanges in time, counted on the device, also where the library would not "
+                    help="SFL_OPT_EXCHANGE_SCHEDULE = 3: exchanges in time, counted on the device, also where the library would not "
                          "choose them by itself (RCCL ranks whose peers are other processes)")
+    ap.add_argument("--no-experiment", action="store_true",
+                    help="multi-GPU runs: skip the extra attempt that times the in-time schedule beside the headline (in_time_experiment)")
     ap.add_argument("--share-device", type=int, default=None, metavar="D",
                     help="multi-rank runs on a box with FEWER GPUs than ranks: every rank process uses device D and tells RCCL it "
                          "is a host of its own (NCCL_HOSTID), so the N processes form a real N-rank communicator over RCCL's "
@@ -343,29 +341,108 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------
 # multi-GPU launch: fresh rank processes per ATTEMPT, a chain of exchange schedules to fall back through
 # ---------------------------------------------------------------------------------------------
-# The three schedules of a slab solve's halo exchanges give the same bits; the fastest one (exchanges in time, counted on
-# the device) waits for messages INSIDE kernels and has never run on more than one real GPU.  A multi-GPU run therefore tries
-# the schedules in this order, each with FRESH rank processes (a process that touched a GPU is never re-executed; a failed
-# attempt's processes are stopped, by PID), and reports which one produced the line and why the earlier ones did not.
-MODES = [("in-time", ["--arrival-in-time"], "in time, counted on the device"),
-         ("by-event", ["--arrival-by-event"], "one launch early, behind events"),
-         ("in-line", ["--no-overlap"], "in line")]
+# The three schedules of a slab solve's halo exchanges give the same bits.  The HEADLINE of a multi-GPU run is what a caller of
+# sfl_poisson_solve gets: the library's own choice of schedule, no flag (on RCCL ranks whose peers are other processes: one launch
+# early, behind events -- ADVICE r05 / VERDICT r05 item 3).  Should that attempt fail, FRESH rank processes try every exchange in
+# line (a process that touched a GPU is never re-executed; a failed attempt's processes are stopped, by PID), and the line says
+# so.  The schedule the library does not pick by itself yet -- exchanges in time, counted on the device: it waits for messages
+# INSIDE kernels and has never run on more than one real GPU -- is timed AFTER a successful headline as a separately labelled
+# experiment (`in_time_experiment`: short, no reference solve, its pressure compared with the headline's by checksum); its
+# failure costs the line nothing.
+PLAN = [("library default", [], "headline"),
+        ("in-line", ["--no-overlap"], "fallback"),
+        ("in-time", ["--arrival-in-time", "--no-cpu-baseline", "--sim-steps", "0", "--halo-timeout-ms", "20000"], "experiment")]
 TOTAL_BUDGET_S = 1500.0
+EXPERIMENT_BUDGET_S = 150.0
 
 
 def attempt_plan(args):
-    """The schedules a multi-GPU run goes through; a schedule asked for on the command line is the only one tried."""
-    if args.arrival_in_time:
-        return [MODES[0]]
-    if args.arrival_by_event:
-        return [MODES[1]]
-    if args.no_overlap:
-        return [MODES[2]]
-    return list(MODES)
+    """(mode, extra flags, role) of the attempts a multi-GPU run goes through; a schedule asked for on the command line is the
+    only one tried."""
+    forced = "in-time" if args.arrival_in_time else "by-event" if args.arrival_by_event else "in-line" if args.no_overlap else None
+    if forced:
+        return [(forced, [], "headline")]
+    return [p for p in PLAN if not (p[2] == "experiment" and args.no_experiment)]
 
 
 def mode_of(args):
     return "in-time" if args.arrival_in_time else "by-event" if args.arrival_by_event else "in-line" if args.no_overlap else "library default"
+
+
+class Attempts:
+    """The bookkeeping both launchers share: which attempt comes next, what the line will say."""
+
+    def __init__(self, args):
+        self.plan, self.k = attempt_plan(args), -1
+        self.t_begin, self.failures, self.headline, self.experiment = time.monotonic(), [], None, None
+        self.args = args
+
+    def next(self):
+        """(mode, flags, role, seconds allowed) of the next attempt to run, or None when there is nothing left to try."""
+        while self.k + 1 < len(self.plan):
+            self.k += 1
+            mode, flags, role = self.plan[self.k]
+            if role == "fallback" and self.headline is not None:
+                continue
+            if role == "experiment" and self.headline is None:
+                continue
+            left = TOTAL_BUDGET_S - (time.monotonic() - self.t_begin)
+            if left < 30.0:
+                if role != "experiment":
+                    self.failures.append({"mode": mode, "why": "not tried: the total budget of the launcher was spent"})
+                else:
+                    self.experiment = {"failed": "not tried: the total budget of the launcher was spent"}
+                continue
+            limit = min(self.args.launch_timeout, left - 10.0)
+            if role == "experiment":
+                limit = min(limit, EXPERIMENT_BUDGET_S)
+            return mode, list(flags), role, limit
+        return None
+
+    def done(self, status, line, why):
+        """Record the outcome of the attempt next() handed out."""
+        mode, _, role = self.plan[self.k]
+        if role == "experiment":
+            self.experiment = summarise_experiment(line, self.headline) if status == 0 and line else {"failed": why, "status": status}
+            return
+        if status == 0 and line:
+            self.headline = annotate(line, mode, list(self.failures))
+        else:
+            self.failures.append({"mode": mode, "status": status, "why": why})
+
+    def upcoming(self):
+        for mode, _, role in self.plan[self.k + 1:]:
+            if role == "fallback" and self.headline is None:
+                return mode
+        return None
+
+    def result(self):
+        """The ONE JSON line of the run, or None when no attempt produced a headline."""
+        if self.headline is None:
+            return None
+        if self.experiment is None:
+            return self.headline
+        d = json.loads(self.headline)
+        d["in_time_experiment"] = self.experiment
+        return json.dumps(d)
+
+
+def summarise_experiment(line, headline):
+    """What the experiment's own line says, next to the headline it is compared with (same grid, same right-hand side)."""
+    try:
+        e, h = json.loads(line), json.loads(headline)
+    except ValueError:
+        return {"failed": "the experiment's line could not be read"}
+    if e.get("dry_run"):
+        return {"dry_run": True, "mode": e.get("mode")}
+    same = e.get("pressure_checksums") is not None and e.get("pressure_checksums") == h.get("pressure_checksums")
+    return {"what": "the same solves with exchanges IN TIME, counted on the device (SFL_OPT_EXCHANGE_SCHEDULE = 3) -- not what the "
+                    "library picks by itself on RCCL ranks whose peers are other processes; fresh rank processes, no reference solve",
+            "value": e.get("value"), "unit": e.get("unit"), "ms_per_step": e.get("ms_per_step"),
+            "exchange_schedule": (e.get("config") or {}).get("exchange_schedule"),
+            "halo_exchanges_per_solve": (e.get("config") or {}).get("halo_exchanges_per_solve"),
+            "pressure_matches_headline_bit_for_bit": bool(same),
+            "vs_headline": (e["value"] / h["value"]) if e.get("value") and h.get("value") else None}
 
 
 class Child:
@@ -418,7 +495,12 @@ class Child:
 
 
 def worker_argv(extra):
-    return [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(extra)
+    """The rank processes run this file again; under tools/with_lib.py (a variant build of the library, SFL_WITH_LIB) they run it
+    through with_lib.py as well, so that a multi-rank A/B run does not silently measure the product library."""
+    me = os.path.abspath(__file__)
+    variant = os.environ.get("SFL_WITH_LIB")
+    head = [sys.executable, os.path.join(os.path.dirname(me), "tools", "with_lib.py"), variant, me] if variant else [sys.executable, me]
+    return head + sys.argv[1:] + list(extra)
 
 
 def launch_ranks(args, extra=(), deadline_s=None):
@@ -499,27 +581,26 @@ def annotate(line, mode, failures):
 
 
 def launch_with_fallback(args):
-    """`python bench.py --gpus N`, N > 1, as typed: the schedules of attempt_plan() one after the other until one gives a
-    line, within TOTAL_BUDGET_S; non-zero with every attempt's reason when none does."""
-    t_begin, failures, status = time.monotonic(), [], 1
-    plan = attempt_plan(args)
-    for k, (mode, flags, _) in enumerate(plan):
-        left = TOTAL_BUDGET_S - (time.monotonic() - t_begin)
-        if left < 30.0:
-            failures.append({"mode": mode, "why": "not tried: the total budget of the launcher was spent"})
-            continue
-        extra = list(flags) if len(plan) > 1 else []
-        if mode == "in-time" and not args.halo_timeout_ms and len(plan) > 1:
-            extra += ["--halo-timeout-ms", "20000"]     # a lost message is to end as an error line, not as a stopped process
-        status, line, why = launch_ranks(args, extra, min(args.launch_timeout, left - 10.0))
-        if status == 0 and line:
-            print(annotate(line, mode if len(plan) > 1 else mode_of(args), failures), flush=True)
-            return 0
-        failures.append({"mode": mode, "status": status, "why": why})
-        if k + 1 < len(plan):
-            print(f"bench.py launcher: schedule '{mode}' failed ({why}); starting fresh ranks with '{plan[k + 1][0]}'",
-                  file=sys.stderr)
-    print("bench.py launcher: every exchange schedule failed: " + json.dumps(failures), file=sys.stderr)
+    """`python bench.py --gpus N`, N > 1, as typed: the attempts of attempt_plan() within TOTAL_BUDGET_S; non-zero with every
+    attempt's reason when none gives a headline."""
+    run = Attempts(args)
+    status = 1
+    while True:
+        nxt = run.next()
+        if nxt is None:
+            break
+        mode, flags, role, limit = nxt
+        status, line, why = launch_ranks(args, flags if len(run.plan) > 1 else [], limit)
+        run.done(status, line, why)
+        if role != "experiment" and run.headline is None and run.upcoming():
+            print(f"bench.py launcher: schedule '{mode}' failed ({why}); starting fresh ranks with '{run.upcoming()}'", file=sys.stderr)
+        if role == "experiment" and "failed" in (run.experiment or {}):
+            print(f"bench.py launcher: the in-time experiment failed ({why}); the headline stands", file=sys.stderr)
+    line = run.result()
+    if line:
+        print(line, flush=True)
+        return 0
+    print("bench.py launcher: every exchange schedule failed: " + json.dumps(run.failures), file=sys.stderr)
     return status or 1
 
 
@@ -535,29 +616,28 @@ def supervise_rank(args):
     Rendezvous = import_module(PKG + ".rendezvous").Rendezvous
     base_key = os.environ.get("SFL_RDZV_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
     sup = Rendezvous(rank, world, key=base_key + "_sup")
-    t_begin, failures, status = time.monotonic(), [], 1
-    plan = attempt_plan(args)
+    run = Attempts(args)
     try:
-        for k, (mode, flags, _) in enumerate(plan):
-            left = TOTAL_BUDGET_S - (time.monotonic() - t_begin)
-            go = sup.all_gather(left >= 30.0)[0]          # rank 0's clock decides for everybody
-            if not go:
-                failures.append({"mode": mode, "why": "not tried: the total budget of the launcher was spent"})
-                continue
-            extra = list(flags) if len(plan) > 1 else []
-            if mode == "in-time" and not args.halo_timeout_ms and len(plan) > 1:
-                extra += ["--halo-timeout-ms", "20000"]
-            env = dict(os.environ, SFL_BENCH_WORKER="1", SFL_RDZV_KEY=f"{base_key}_w{k}",
+        while True:
+            nxt = run.next()
+            nxt = sup.all_gather(nxt)[0]          # rank 0's clock decides for everybody
+            if nxt is None:
+                break
+            mode, flags, role, limit = nxt
+            if rank != 0:                          # (keep every rank's bookkeeping on the attempt rank 0 named)
+                run.k = next(i for i, p in enumerate(run.plan) if p[0] == mode)
+            extra = flags if len(run.plan) > 1 else []
+            env = dict(os.environ, SFL_BENCH_WORKER="1", SFL_RDZV_KEY=f"{base_key}_w{run.k}",
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             kid = Child(worker_argv(extra), env, keep_stdout=(rank == 0))
-            deadline = time.monotonic() + min(args.launch_timeout, left - 10.0)
+            deadline = time.monotonic() + limit
             verdict = None
             while verdict is None:
                 time.sleep(0.25)
                 rc = kid.poll()
                 mine = "running" if rc is None else ("ok" if rc == 0 else f"rank {rank} exited with status {rc}: {kid.last_err or 'no message'}")
                 if rank == 0 and rc is None and time.monotonic() > deadline:
-                    mine = f"no result after {min(args.launch_timeout, left - 10.0):.0f} s"
+                    mine = f"no result after {limit:.0f} s"
                 states = sup.all_gather(mine)
                 broken = [st for st in states if st not in ("running", "ok")]
                 if broken:
@@ -566,21 +646,25 @@ def supervise_rank(args):
                     verdict = "ok"
             kid.stop()
             kid.finish()
-            if verdict == "ok":
-                line = kid.json_line() if rank == 0 else None
-                if rank != 0 or line:
-                    if rank == 0:
-                        print(annotate(line, mode if len(plan) > 1 else mode_of(args), failures), flush=True)
-                    status = 0
-                    sup.barrier()
-                    return 0
+            line = kid.json_line() if (rank == 0 and verdict == "ok") else None
+            if verdict == "ok" and rank == 0 and not line:
                 verdict = "rank 0 printed no JSON line"
-            failures.append({"mode": mode, "why": verdict})
-            if rank == 0 and k + 1 < len(plan):
-                print(f"bench.py: schedule '{mode}' failed ({verdict}); starting fresh ranks with '{plan[k + 1][0]}'", file=sys.stderr)
+            verdict = sup.all_gather(verdict)[0]   # (rank 0 may have found its line missing)
+            ok = verdict == "ok"
+            # every rank keeps the same bookkeeping; only rank 0 holds the lines themselves
+            run.done(0 if ok else 1, line if rank == 0 else ("{}" if ok else None), None if ok else verdict)
+            if rank == 0 and role != "experiment" and not ok and run.upcoming():
+                print(f"bench.py: schedule '{mode}' failed ({verdict}); starting fresh ranks with '{run.upcoming()}'", file=sys.stderr)
+            if rank == 0 and role == "experiment" and not ok:
+                print(f"bench.py: the in-time experiment failed ({verdict}); the headline stands", file=sys.stderr)
+        if run.headline is not None:
+            if rank == 0:
+                print(run.result(), flush=True)
+            sup.barrier()
+            return 0
         if rank == 0:
-            print("bench.py: every exchange schedule failed: " + json.dumps(failures), file=sys.stderr)
-        return status or 1
+            print("bench.py: every exchange schedule failed: " + json.dumps(run.failures), file=sys.stderr)
+        return 1
     finally:
         sup.close()
 
@@ -654,15 +738,13 @@ def run_rank(args):
     else:
         s = sfl.Solver(size, dim_y, device=local_rank, rank=rank, nranks=world)
     if args.no_overlap:
-        s.set_option(capi.OPT_SOR_OVERLAP, 0)
+        s.set_option(capi.OPT_EXCHANGE_SCHEDULE, capi.SCHEDULE_IN_LINE)
     if args.arrival_by_event:
-        s.set_option(capi.OPT_SOR_ARRIVAL, 0)
+        s.set_option(capi.OPT_EXCHANGE_SCHEDULE, capi.SCHEDULE_BY_EVENT)
     if args.arrival_in_time:
-        s.set_option(capi.OPT_SOR_ARRIVAL, 1)
+        s.set_option(capi.OPT_EXCHANGE_SCHEDULE, capi.SCHEDULE_IN_TIME)
     if args.halo_timeout_ms:
         s.set_option(capi.OPT_HALO_TIMEOUT_MS, args.halo_timeout_ms)
-    if args.chain is not None:
-        s.set_option(capi.OPT_SOR_CHAIN, args.chain)
     for opt, val in ((capi.OPT_SOR_FUSE, args.fuse), (capi.OPT_SOR_KERNEL, args.sor_kernel),
                      (capi.OPT_SOR_ROWS, args.sor_rows), (capi.OPT_SOR_LANE_CELLS, args.lane_cells),
                      (capi.OPT_SOR_HALO, args.sor_halo), (capi.OPT_ADVECT_KERNEL, args.advect_kernel)):
@@ -730,19 +812,20 @@ def run_rank(args):
     info = s.last_solve_info()
     schedule = s.get_option(capi.OPT_EXCHANGE_SCHEDULE)
     exchange_us = s.get_option(capi.OPT_MEASURED_WIRE_US)    # -1: nothing to measure (one GPU)
-    try:
-        info["chained"] = s.get_option(capi.OPT_LAST_CHAINED)   # supersteps of the last solve inside chained launches
-    except sfl.SflError:                                        # (an older library under tools/with_lib.py)
-        info["chained"] = 0
 
     # ---- parity of the timed configuration: the p the last timed solve left behind is downloaded
     # NOW (with the right-hand side it was solved for); the reference CPU loop runs after all GPU
     # timing is done -- it keeps the host busy for seconds, during which the GPU clocks fall back
     parity, cpu_rec = None, None
     want_parity = not args.no_cpu_baseline and not (world > 1 and args.no_parity)
-    if want_parity:
+    got = None
+    if want_parity or (world > 1 and not emulate):
         got = s.download(capi.FIELD_PRESSURE)
+    if want_parity:
         d_own = s.download(capi.FIELD_DIVERGENCE)
+    # every rank's rows of the timed solve's pressure as checksums (multi-GPU lines: two attempts of one run -- the headline and the
+    # in-time experiment -- are compared through them without a second reference solve)
+    p_sums = rdzv.all_gather(slab_checksums([got])[0] if got is not None else None) if (world > 1 and not emulate) else None
 
     # ---- full sim step, timed separately (not part of `value`) ---------------------------------
     # A slab reports a back-trace that left its advection halo at synchronize(); every rank still
@@ -897,7 +980,6 @@ def run_rank(args):
             (cells * iters / unprimed * 1e3) if unprimed else None,
             "cell_iters_per_sec_of_this_rank": cells * iters * args.steps / elapsed,
             "sor_launches_per_solve": info["launches"], "halo_exchanges_per_solve": info["exchanges"],
-            "supersteps_in_chained_launches": info["chained"],
             "half_sweeps_fused_per_launch": info["fuse"], "overlap": not args.no_overlap,
             "emulated_wire_us": args.wire_us, "transport": "rccl-to-self" if args.via_rccl else "copy-kernel",
             "exchange_schedule": SCHEDULES.get(schedule, schedule),
@@ -994,7 +1076,6 @@ def run_rank(args):
                                        "say nothing about xGMI or scaling" if shared_device is not None and world > 1 else ""),
                        **({"physical_gpus": 1, "ranks_share_device": local_rank} if shared_device is not None and world > 1 else {}),
                        "sor_launches_per_solve": info["launches"],
-                       "supersteps_in_chained_launches": info["chained"],
                        "halo_exchanges_per_solve": info["exchanges"],
                        "exchange_schedule": SCHEDULES.get(schedule, schedule),
                        "halo_rows_per_superstep": info["halo"], "measured_exchange_latency_us": exchange_us,
@@ -1017,6 +1098,7 @@ def run_rank(args):
                    if other_arith else {}),
             },
             "parity": parity,
+            **({"pressure_checksums": p_sums} if p_sums is not None else {}),
             **({"sim_step_parity": step_parity} if step_parity is not None else {}),
             "roofline": roofline,
             "sim_steps_per_sec": sim_sps,

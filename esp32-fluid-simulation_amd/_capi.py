@@ -14,18 +14,15 @@ OPT_SOR_KERNEL, OPT_SOR_FUSE, OPT_ADVECT_HALO, OPT_SOR_ROWS, OPT_TRANSPORT = 0, 
 OPT_SOR_LANE_CELLS = 5
 OPT_SOR_HALO = 6
 OPT_FUSE_PROJECTION = 7
-OPT_SOR_OVERLAP = 8
 OPT_ADVECT_KERNEL = 9
 OPT_FUSE_DIVERGENCE = 10
 OPT_SMALL_GRID = 11
 OPT_EMULATE_WIRE_US = 12
-OPT_SOR_ARRIVAL = 13
 OPT_STEP_SEAMS = 14
-OPT_SOR_CHAIN = 15
-OPT_LAST_CHAINED = 16
 OPT_LAST_EARLY_ROWS = 17
 OPT_HALO_TIMEOUT_MS = 18
 OPT_EXCHANGE_SCHEDULE = 19
+SCHEDULE_AUTO, SCHEDULE_IN_LINE, SCHEDULE_BY_EVENT, SCHEDULE_IN_TIME = 0, 1, 2, 3   # values of OPT_EXCHANGE_SCHEDULE
 OPT_MEASURED_WIRE_US = 20
 OPT_LAST_HALO = 21
 OPT_SOR_FOLD = 22

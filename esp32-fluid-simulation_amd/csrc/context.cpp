@@ -142,7 +142,7 @@ int check_wait_error(sfl_context *c)
 // (slabs only) has a wait inside one of this context's launches given up?  The stream has just been drained.
 static int look_for_wait_error(sfl_context *c)
 {
-    if (c->nranks < 2 && !c->d_chain) return SFL_OK;
+    if (c->nranks < 2) return SFL_OK;
     int word = 0;
     HIP_TRY(hipMemcpy(&word, c->halo_flag + 2, sizeof word, hipMemcpyDeviceToHost));
     if (word) c->wait_error_seen = true;
@@ -292,11 +292,12 @@ int sfl_create_slab(sfl_context **out, int device, int dim_x, int dim_y, int ran
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
     void *flag = nullptr;
-    HIP_TRY(hipMalloc(&flag, 4 * sizeof(int)));
-    HIP_TRY(hipMemset(flag, 0, 4 * sizeof(int)));
+    HIP_TRY(hipMalloc(&flag, (4 + kCollectiveWords) * sizeof(int)));
+    HIP_TRY(hipMemset(flag, 0, (4 + kCollectiveWords) * sizeof(int)));
     c->halo_flag = static_cast<int *>(flag);
     c->d_arrival = c->halo_flag + 1;
     c->d_done = c->halo_flag + 3;
+    c->d_collective = c->halo_flag + 4;
     *out = c.release();
     return SFL_OK;
 }
@@ -326,7 +327,7 @@ int sfl_destroy(sfl_context *c)
     c->transport.reset();   // (an RCCL transport destroys its communicator)
     c->keepalive.reset();
     for (void *m : {(void *)c->vel, (void *)c->vel_tmp, (void *)c->col, (void *)c->col_tmp,
-                    (void *)c->sor_block, (void *)c->halo_flag, (void *)c->d_chain,
+                    (void *)c->sor_block, (void *)c->halo_flag,
                     (void *)c->d_force_cells, (void *)c->d_force_vel, (void *)c->d_image,
                     (void *)c->host_scratch, (void *)c->d_reach, c->gather_buf})
         if (m) (void)hipFree(m);
@@ -353,6 +354,16 @@ int sfl_destroy(sfl_context *c)
     return SFL_OK;
 }
 
+// What one exchange costs depends on the protocol it was measured with: forget it -- and the halo depths that were chosen from it
+// (a depth decided for another exchange cost must not outlive it) -- and measure again before the next solve.
+static void invalidate_exchange_measurement(sfl_context *c)
+{
+    c->exchange_latency_us = -1;
+    HaloTuner &t = c->group ? c->group->halo_tuner : c->halo_tuner;
+    t.decided.clear();
+    t.active = false;
+}
+
 static int set_option_one(sfl_context *c, int option, int value)
 {
     switch (option) {
@@ -372,23 +383,26 @@ static int set_option_one(sfl_context *c, int option, int value)
             return SFL_OK;
         case SFL_OPT_SOR_ROWS:
             if (value < 0) return fail(SFL_ERR_INVALID, "rows per chunk must be >= 0");
+            if (value != c->opt_sor_rows) invalidate_exchange_measurement(c);   // (the timed solves the halo depth was chosen from ran on other tiles)
             c->opt_sor_rows = value;
             return SFL_OK;
         case SFL_OPT_TRANSPORT:
             return fail(SFL_ERR_INVALID, "SFL_OPT_TRANSPORT is read-only: use sfl_comm_attach / sfl_group_link");
-        case SFL_OPT_LAST_CHAINED:
         case SFL_OPT_LAST_EARLY_ROWS:
-        case SFL_OPT_EXCHANGE_SCHEDULE:
         case SFL_OPT_MEASURED_WIRE_US:
         case SFL_OPT_LAST_HALO:
             return fail(SFL_ERR_INVALID, "this option is read-only");
         case SFL_OPT_FUSE_PROJECTION:
             c->opt_fuse_projection = value ? 1 : 0;
             return SFL_OK;
-        case SFL_OPT_SOR_OVERLAP:
-            if (c->opt_sor_overlap != (value ? 1 : 0)) c->exchange_latency_us = -1;
-            c->opt_sor_overlap = value ? 1 : 0;
+        case SFL_OPT_EXCHANGE_SCHEDULE: {   // 0 automatic, 1 in line, 2 one launch early behind events, 3 in time
+            if (value < 0 || value > 3) return fail(SFL_ERR_INVALID, "exchange schedule must be 0 (auto), 1 (in line), 2 (behind events) or 3 (in time)");
+            const int overlap = value == 1 ? 0 : 1, arrival = value == 2 ? 0 : value == 3 ? 1 : -1;
+            if (overlap != c->opt_sor_overlap || arrival != c->opt_sor_arrival) invalidate_exchange_measurement(c);   // (measured with the other protocol)
+            c->opt_sor_overlap = overlap;
+            c->opt_sor_arrival = arrival;
             return SFL_OK;
+        }
         case SFL_OPT_FUSE_DIVERGENCE:
             c->opt_fuse_divergence = value ? 1 : 0;
             return SFL_OK;
@@ -402,11 +416,7 @@ static int set_option_one(sfl_context *c, int option, int value)
         case SFL_OPT_EMULATE_WIRE_US:
             if (value < 0 || value > 10000) return fail(SFL_ERR_INVALID, "emulated wire delay must be 0..10000 us");
             c->opt_emulate_wire_us = value;
-            c->exchange_latency_us = -1;   // what an exchange costs is measured again before the next solve
-            return SFL_OK;
-        case SFL_OPT_SOR_ARRIVAL:
-            if (c->opt_sor_arrival != (value < 0 ? -1 : (value ? 1 : 0))) c->exchange_latency_us = -1;   // (measured with the other protocol)
-            c->opt_sor_arrival = value < 0 ? -1 : (value ? 1 : 0);
+            invalidate_exchange_measurement(c);   // what an exchange costs is measured again before the next solve
             return SFL_OK;
         case SFL_OPT_HALO_TIMEOUT_MS:
             if (value < 0) return fail(SFL_ERR_INVALID, "halo timeout must be >= 0 ms (0 = the transport's default)");
@@ -417,10 +427,6 @@ static int set_option_one(sfl_context *c, int option, int value)
             return SFL_OK;
         case SFL_OPT_SOR_FOLD:
             c->opt_sor_fold = value ? 1 : 0;
-            return SFL_OK;
-        case SFL_OPT_SOR_CHAIN:
-            if (value < -1) return fail(SFL_ERR_INVALID, "SFL_OPT_SOR_CHAIN must be -1 (auto), 0, 1 or a number of waves >= 8");
-            c->opt_sor_chain = value;   // >= 8: on, with at most that many waves per chain (several tiles per wave: a test aid)
             return SFL_OK;
         case SFL_OPT_SOR_HALO:
             if (value != 0 && (value < 2 || value > kGhostRows))
@@ -464,9 +470,8 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_TRANSPORT: *value = c->transport ? c->transport->kind() : 0; return SFL_OK;
         case SFL_OPT_HALO_TIMEOUT_MS: *value = c->opt_halo_timeout_ms; return SFL_OK;
         case SFL_OPT_LAST_HALO: *value = c->last_halo; return SFL_OK;
-        case SFL_OPT_MEASURED_WIRE_US:
-            if (c->transport && c->nranks > 1 && c->exchange_latency_us < 0) SFL_TRY(measure_exchange(c));
-            *value = c->exchange_latency_us;
+        case SFL_OPT_MEASURED_WIRE_US:   // (a query only: measuring is a COLLECTIVE of the ranks and belongs to the next solve, resolve_schedule)
+            *value = c->transport && c->nranks > 1 ? c->exchange_latency_us : -1;
             return SFL_OK;
         case SFL_OPT_EXCHANGE_SCHEDULE: {   // what the next solve will do: needs the streams' verdict (transport.cpp)
             if (!c->transport || c->nranks < 2 || c->opt_sor_kernel == 1) { *value = 0; return SFL_OK; }
@@ -479,15 +484,11 @@ int sfl_get_option(sfl_context *c, int option, int *value)
         case SFL_OPT_SOR_LANE_CELLS: *value = c->opt_sor_lane_cells; return SFL_OK;
         case SFL_OPT_SOR_HALO: *value = c->opt_sor_halo; return SFL_OK;
         case SFL_OPT_FUSE_PROJECTION: *value = c->opt_fuse_projection; return SFL_OK;
-        case SFL_OPT_SOR_OVERLAP: *value = c->opt_sor_overlap; return SFL_OK;
         case SFL_OPT_ADVECT_KERNEL: *value = c->opt_advect_kernel; return SFL_OK;
         case SFL_OPT_FUSE_DIVERGENCE: *value = c->opt_fuse_divergence; return SFL_OK;
         case SFL_OPT_SMALL_GRID: *value = c->opt_small_grid; return SFL_OK;
         case SFL_OPT_EMULATE_WIRE_US: *value = c->opt_emulate_wire_us; return SFL_OK;
-        case SFL_OPT_SOR_ARRIVAL: *value = c->opt_sor_arrival; return SFL_OK;
         case SFL_OPT_STEP_SEAMS: *value = c->opt_step_seams; return SFL_OK;
-        case SFL_OPT_SOR_CHAIN: *value = c->opt_sor_chain; return SFL_OK;
-        case SFL_OPT_LAST_CHAINED: *value = c->last_chained; return SFL_OK;
         case SFL_OPT_LAST_EARLY_ROWS: *value = c->last_early_kept; return SFL_OK;
     }
     return fail(SFL_ERR_INVALID, "unknown option %d", option);
@@ -561,7 +562,7 @@ int sfl_synchronize(sfl_context *ctx)
     for (sfl_context *c : peers_of(ctx)) {
         SFL_TRY(use_device(c));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->nranks > 1 || c->d_chain) {
+        if (c->nranks > 1) {
             int words[3] = {0, 0, 0};   // halo_flag, arrival count, a wait for it timed out
             HIP_TRY(hipMemcpy(words, c->halo_flag, sizeof words, hipMemcpyDeviceToHost));
             if (words[0]) {
@@ -571,8 +572,7 @@ int sfl_synchronize(sfl_context *ctx)
             }
             if (words[2]) {
                 HIP_TRY(hipMemset(c->halo_flag + 2, 0, sizeof(int)));
-                // bits: 1 a tile of a launch, 4 a tile of a chained launch, 8 the exchange stream (for the sender count) waited
-                // for a halo message; 2 a tile of a chained launch for the tiles around it
+                // bits: 1 a tile of a launch, 8 the exchange stream (for the sender count) waited for a halo message
                 rc = fail(SFL_ERR_HIP, "slab %d/%d: a wait inside a solve lasted longer than %g s (waits 0x%x; arrival "
                           "count %d of %d): the pressure field is not valid", c->rank, c->nranks,
                           halo_timeout_us(c) / 1e6, words[2], words[1], c->arrival_epoch);

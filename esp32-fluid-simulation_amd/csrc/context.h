@@ -5,7 +5,7 @@
 //   transport.{h,cpp} halo transports behind one interface (virtual-rank group, RCCL, emulated rank), the exchange
 //                     protocol around them, communicator attach / option check
 //   sor_executor.cpp  poisson_solve: walks slab_plan.h programs (in line, early exchanges behind events, exchanges in
-//                     time counted on the device, chained launches)
+//                     time counted on the device)
 //   operators.cpp     advection, divergence, projection, forces, setup / render
 //   slab_step.cpp     sfl_step / sfl_step_n, the automatic advection halo of a slab's step
 //   host_dropin.cpp   the host-pointer drop-ins (sfl_host_*) and their per-thread context
@@ -78,6 +78,8 @@ class Group;
 // measured exchange as its input names up to three candidate depths, each of the first solves of a kind -- same iteration
 // count, fuse depth, tail and schedule -- runs on one of them between two events (every depth gives the same bits), and the
 // fastest is kept for that kind from then on (another depth has to beat the legacy one by 1.5 %).
+constexpr int kCollectiveWords = 8;   // sfl_context::d_collective
+
 struct HaloTuner {
     struct Kind {
         int iters, fuse, tail, in_time;
@@ -138,11 +140,10 @@ struct sfl_context {
     int *d_arrival = nullptr;      // [1] halo messages arrived (and relaxed) so far: what cut-adjacent tiles poll inside a
                                    //     launch (kernels.h HaloWait); [2] such a wait timed out
     int arrival_epoch = 0;         // the last value queued for [1]
+    int *d_collective = nullptr;   // [4 .. 4 + kCollectiveWords) scratch of the ranks' small reductions (measure_exchange, the halo tuner): allocated
+                                   //     with the context, so that no rank can drop out of a collective over a failed allocation
     int *d_done = nullptr;         // [3] sender tiles finished so far (kernels.h HaloWait::done): what the exchange stream waits
     int done_target = 0;           //     for before a halo message leaves; done_target = the count the launches queued so far reach
-    int *d_chain = nullptr;        // one word per tile of a chained launch (kernels.h launch_sor_chain), allocated on first use
-    int chain_words = 0;
-    int chain_epoch = 0;           // the words only count up: the next chained launch starts from here
     bool wait_error_seen = false;  // word [2] was found raised (download, a step's report): every call fails until sfl_synchronize
                                    // has reported and cleared it
 
@@ -202,11 +203,12 @@ struct sfl_context {
     uint64_t known_epoch = 0, vel_epoch = 1;   // vel_epoch counts the writes to the velocity field
     float known_dt = 0.0f;
 
-    // SFL_OPT_SOR_ARRIVAL: -1 = automatic (the transport's choice, Transport::arrival_by_default), 0 / 1 as set
+    // the two halves of SFL_OPT_EXCHANGE_SCHEDULE: opt_sor_overlap 0 = in line (1); opt_sor_arrival -1 = automatic (the transport's choice,
+    // Transport::arrival_by_default), 0 = behind events (2), 1 = in time (3)
     int opt_sor_kernel = 0, opt_sor_fuse = 0, opt_advect_halo = 0, opt_sor_rows = 0,
         opt_sor_lane_cells = 0, opt_sor_halo = 0, opt_fuse_projection = 1, opt_sor_overlap = 1,
         opt_advect_kernel = 0, opt_fuse_divergence = 1, opt_small_grid = 1, opt_emulate_wire_us = 0, opt_sor_arrival = -1,
-        opt_step_seams = 1, opt_sor_chain = 0, opt_halo_timeout_ms = 0, opt_sor_fold = 0;
+        opt_step_seams = 1, opt_halo_timeout_ms = 0, opt_sor_fold = 0;
 
     // how halo rows reach the neighbouring slabs (transport.h); null on a whole-domain context and on a slab that has
     // not been attached / linked yet.  `group` = the same object when it is an in-process group of virtual ranks.
@@ -222,7 +224,7 @@ struct sfl_context {
     int last_halo = 0;                  // halo depth of the last solve's plan (SFL_OPT_LAST_HALO)
     sfl::host::HaloTuner halo_tuner;    // (a linked group keeps its own: Group::halo_tuner)
 
-    int last_launches = 0, last_exchanges = 0, last_fuse = 0, last_chained = 0;
+    int last_launches = 0, last_exchanges = 0, last_fuse = 0;
     int solve_tail = 0;   // ghost rows of p the next solve must leave exact (slab_step_auto: 1, for subtract_gradient)
     int p_ghost_valid = 0;  // ghost rows of p that are exact right now (set by the solve, cleared by whoever writes p)
     int v_ghost_valid = 0;  // ghost rows of the velocity that are exact right now (slab_step_auto advects own +- 1 rows)
@@ -265,7 +267,7 @@ SorParams sor_params(const sfl_context *c, float dx, float omega);
 bool small_grid(const sfl_context *c);
 // halo timeout of the waits inside this context's launches, microseconds (kernels.h HaloWait::timeout_us)
 int halo_timeout_us(const sfl_context *c);
-// will the next solve count its halo exchanges on the device (SFL_OPT_SOR_ARRIVAL resolved; the streams' verdict is in)?
+// will the next solve count its halo exchanges on the device (SFL_OPT_EXCHANGE_SCHEDULE resolved; the streams' verdict is in)?
 bool in_time_exchanges(const sfl_context *c);
 // halo depth of a solve's supersteps: the option, or chosen from the measured exchange (sor_executor.cpp)
 int effective_halo(const sfl_context *c, int fuse, int iters, bool in_time);

@@ -154,37 +154,6 @@ hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, cons
                             Slab g, SorRows rows, int nsweeps, int first_colour,
                             SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait = nullptr,
                             int *senders = nullptr);   // *senders = tiles of this launch that will add to *wait->done
-// CHAINED supersteps: up to kMaxChain consecutive launches of launch_sor_fused (same fuse depth, not from zero) as ONE launch.
-// Every wave of the launch owns the tiles slot, slot + waves, ... of each superstep and goes from one superstep to the next
-// without a launch boundary: a tile waits only for the tiles of the previous superstep whose output it reads or whose input it
-// overwrites (three strips x the chunks within NS + 3 rows: sor::chunks_touching), found through one word per tile in `flags`
-// (`flag_words` of them, at least as many as the largest superstep has tiles; zero once, then never reset: the values only
-// count up, `epoch` + superstep + 1 -- the next chained launch passes an epoch beyond this one's last value).  p is stored written-through and loaded past the CU's L1 (sc1 both ways: no fence anywhere);
-// a finished tile drains its stores and then publishes its word.  Superstep i reads `pa` when i is even and `pb` when it is odd,
-// and writes the other.  steps[i].hw carries the halo protocol of that superstep exactly as for launch_sor_fused (arrival to wait
-// for, sender tiles to count); senders[i] receives the number of its sender tiles.  `max_waves` bounds the waves of the launch
-// (0: what is resident on the device at once) -- every wave must be resident for the chain to make progress, so callers that
-// run other work beside it leave room.  A wait of more than steps[0].hw.timeout_us raises *timed_out.  Requires what the 8-byte
-// path requires (even dim_x, 8-byte aligned arrays) and a fuse depth in {8, 10, 12, 16}: sor_chain_supported.
-constexpr int kMaxChain = 16;
-struct ChainStep {
-    int g_begin, g_end;   // output rows
-    int sweep;            // stream-direction parity (launch_sor_fused's `sweep`)
-    HaloWait hw;
-    // The halo message sent behind superstep e is READ from the array that superstep e + 2 writes.  Between launches the
-    // order is implied (e + 1 ends after its cut-adjacent tiles have seen the arrival count, which the exchange stream raises
-    // after the send as well); inside a chain it has to be said: tiles of this superstep whose output rows reach below
-    // guard_lo_end or above guard_hi_begin -- the rows that message carried -- first wait until *guard_flag has reached
-    // guard_epoch.  guard_flag == nullptr: no such message.
-    const int *guard_flag;
-    int guard_epoch, guard_lo_end, guard_hi_begin;
-};
-bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps);
-// `tiles_at_most` > 0: launch only if no superstep has more tiles than that (the chain pays where every tile is resident at two
-// waves per SIMD: thin slabs), *launched says which; 0: always.
-hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
-                            int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch,
-                            int *timed_out, int max_waves, int *senders, int tiles_at_most = 0, bool *launched = nullptr);
 // *flag = value, visible to every CU (stream-ordered behind the message / the kernels that relaxed it)
 hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value);
 // One wave that returns when *count has reached `target` (signed distance; sender tiles of launches on ANOTHER stream

@@ -1,11 +1,13 @@
 // sor_executor.cpp -- poisson_solve (poisson.cpp:114-125) on a context: walks the launch / exchange program of
 // slab_plan.h.  Three schedules for the halo exchanges of a slab (all the same bits):
-//   in line            every launch whole, every exchange awaited (SFL_OPT_SOR_OVERLAP = 0, the baseline kernel)
+//   in line            every launch whole, every exchange awaited (SFL_OPT_EXCHANGE_SCHEDULE = 1, the baseline kernel)
 //   early, by events   the halo of a superstep travels one launch early on the exchange stream, its ghost rows are
-//                      relaxed behind the message, the launch after waits for an event (SFL_OPT_SOR_ARRIVAL = 0)
+//                      relaxed behind the message, the launch after waits for an event (SFL_OPT_EXCHANGE_SCHEDULE = 2)
 //   in time, counted   the halo follows the launch that produces it; sender tiles count themselves, the message leaves
 //                      on that count, only the next launch's cut-adjacent tiles wait -- inside the kernel -- for a
-//                      count of arrivals (SFL_OPT_SOR_ARRIVAL = 1; optionally as chained launches, SFL_OPT_SOR_CHAIN)
+//                      count of arrivals (SFL_OPT_EXCHANGE_SCHEDULE = 3)
+// (Round 4's fourth executor -- the launches of a solve as ONE chained launch -- bought -4 .. +3 % on the emulated ranks and was
+// retired in round 6: DESIGN.md 6, history up to commit 77c9c76.)
 // Host C++ only; the kernels live in sor_fused.hip / stencil_kernels.hip / small_grid.hip.
 #include "transport.h"
 
@@ -196,17 +198,15 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, int 
         if (us[0] == 1 << 30) us[0] = 0;   // (nothing usable: the legacy depth)
     }
     if (t.ncand > 1 && reduces_on_device(ctx)) {
-        int *dev = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&dev), sizeof us) == hipSuccess) {
-            Overlap o;
-            const bool ok = hipMemcpy(dev, us, sizeof us, hipMemcpyHostToDevice) == hipSuccess && overlap_of(ctx, &o) == SFL_OK &&
-                            ctx->transport->allreduce_max(ctx, dev, HaloTuner::kCandidates, o.xstream) == SFL_OK &&
-                            hipStreamSynchronize(o.xstream) == hipSuccess &&
-                            hipMemcpy(us, dev, sizeof us, hipMemcpyDeviceToHost) == hipSuccess;
-            (void)hipFree(dev);
-            if (!ok)
-                for (int k = 1; k < t.ncand; ++k) us[k] = 1 << 30;   // (then the legacy depth, on every rank that got this far)
-        }
+        // (the context's own scratch words: no allocation that could fail on one rank and leave the others in the reduction alone)
+        int *dev = ctx->d_collective;
+        Overlap o;
+        static_assert(HaloTuner::kCandidates <= kCollectiveWords, "scratch words of the ranks' reductions");
+        if (hipMemcpy(dev, us, sizeof us, hipMemcpyHostToDevice) != hipSuccess) (void)hipMemset(dev, 0x7f, sizeof us);
+        const bool ok = overlap_of(ctx, &o) == SFL_OK && ctx->transport->allreduce_max(ctx, dev, HaloTuner::kCandidates, o.xstream) == SFL_OK &&
+                        hipStreamSynchronize(o.xstream) == hipSuccess && hipMemcpy(us, dev, sizeof us, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok)
+            for (int k = 1; k < t.ncand; ++k) us[k] = 1 << 30;   // (then the legacy depth, on every rank that got this far)
     }
     int best = 0;
     for (int k = 1; k < t.ncand; ++k)
@@ -221,7 +221,7 @@ static int choose_halo(sfl_context *ctx, int fuse, int iters, bool in_time, int 
     return t.cand[best];
 }
 
-// Exchanges IN TIME with everything counted on the device (run_poisson_in_time; SFL_OPT_SOR_ARRIVAL) instead of early exchanges
+// Exchanges IN TIME with everything counted on the device (run_poisson_in_time; SFL_OPT_EXCHANGE_SCHEDULE = 3) instead of early exchanges
 // behind cross-stream events: slabs with a transport, the fused kernel, exchanges overlapped -- where the transport takes it by
 // default (Transport::arrival_by_default) or the option asks for it, and only where the compute and the exchange stream were
 // seen to run side by side (resolve_schedule: a launch that waits inside the kernel must not sit in front of its message).
@@ -317,190 +317,7 @@ int exec_sor_step(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams 
     return SFL_OK;
 }
 
-// ---- chained supersteps (kernels.h launch_sor_chain; SFL_OPT_SOR_CHAIN) ---------------------------------------------------
-// May plan steps [i, i + n) of `prog` go into one chained launch?  SOR steps of one supported fuse depth, none from zero.
-int chainable_steps(const sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, bool across_exchanges)
-{
-    if (c->opt_sor_chain <= 0 || effective_kernel(c) != 2) return 0;   // (automatic: only where exchanges run in time, below)
-    int n = 0;
-    size_t k = i;
-    for (; k < prog.size() && n < sfl::kMaxChain; ++k) {
-        const sfl_plan_step &st = prog[k];
-        if (st.kind == SFL_STEP_EXCHANGE && across_exchanges && st.field == SFL_FIELD_PRESSURE && n > 0) continue;
-        if (st.kind != SFL_STEP_SOR || st.from_zero || st.first_colour != 0 || st.nsweeps != prog[i].nsweeps ||
-            st.g_end <= st.g_begin)
-            break;
-        ++n;
-    }
-    if (n < 2 || !sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, prog[i].nsweeps)) return 0;
-    return n;
-}
-
-int ensure_chain_words(sfl_context *c)
-{
-    if (c->d_chain) return SFL_OK;
-    // more words than any tiling of the slab has tiles: strips of >= 96 kept columns x chunks of >= kMinEdgeRows rows
-    const int words = 32 * (c->dim_x / 96 + 3) * (c->geom.lrows / 8 + 4);   // a 128-byte line per tile
-    void *m = nullptr;
-    SFL_TRY(use_device(c));
-    HIP_TRY(hipMalloc(&m, (size_t)words * sizeof(int)));
-    HIP_TRY(hipMemsetAsync(m, 0, (size_t)words * sizeof(int), c->stream));
-    c->d_chain = static_cast<int *>(m);
-    c->chain_words = words;
-    return SFL_OK;
-}
-
-// Plan steps [i, i + n) of a context whose launches need no halo protocol (whole domains, the in-line order), as one launch.
-int exec_sor_chain(sfl_context *c, const std::vector<sfl_plan_step> &prog, size_t i, int n, const sfl::SorParams &prm)
-{
-    SFL_TRY(ensure_chain_words(c));
-    sfl::ChainStep steps[sfl::kMaxChain];
-    for (int k = 0; k < n; ++k) {
-        const sfl_plan_step &st = prog[i + k];
-        steps[k].g_begin = st.g_begin;
-        steps[k].g_end = st.g_end;
-        steps[k].sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + k : 0;
-        steps[k].hw = sfl::HaloWait{nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0};
-        steps[k].guard_flag = nullptr;
-        steps[k].guard_epoch = steps[k].guard_lo_end = steps[k].guard_hi_begin = 0;
-    }
-    HIP_TRY(sfl::launch_sor_chain(c->stream, c->p, c->p_alt, c->div, c->geom, steps, n, prog[i].nsweeps, prm, c->opt_sor_rows,
-                                  c->d_chain, c->chain_words, c->chain_epoch, c->d_arrival + 1,
-                                  c->opt_sor_chain >= 8 ? c->opt_sor_chain & ~3 : 0, nullptr));
-    c->chain_epoch += n + 1;
-    if (n & 1) std::swap(c->p, c->p_alt);
-    c->last_launches += n;
-    c->last_chained += n;
-    return SFL_OK;
-}
-// The rows the last p halo message of a solve was read from, and how many supersteps have been issued since: the superstep
-// two behind a message overwrites its source (kernels.h ChainStep::guard_flag).
-struct SentBand {
-    bool valid = false;
-    int epoch = 0, lo_end = 0, hi_begin = 0, age = 0;
-};
-
-// In-time exchanges with the launches CHAINED (SFL_OPT_SOR_CHAIN): the SOR steps from step i on -- up to kMaxChain, p exchanges
-// between and behind them included -- as one chained launch per context, with the exchange stream's work (wait for the sender
-// counts, copy / send, raise the arrival counts) queued behind them exactly as for single launches.  The chains of the virtual
-// ranks of a group wait for each other's messages, so they must RUN side by side: the first on the compute stream, the others
-// on a stream of their own each (joined back into the compute stream), all of them within a budget of waves that is resident
-// at once.  *next = first plan step not consumed (== i: nothing was chained).
-int chain_in_time(const std::vector<sfl_context *> &peers, const std::vector<std::vector<sfl_plan_step>> &progs, size_t i,
-                  const sfl::SorParams &prm, const Overlap &o, bool *flagged, std::vector<SentBand> *bands, size_t *next)
-{
-    *next = i;
-    const std::vector<sfl_plan_step> &prog = progs[0];   // every rank's program has the same shape
-    std::vector<size_t> sor;
-    std::vector<long> xch;   // the p exchange behind sor[k] (index into prog), or -1
-    size_t k = i;
-    const int ns = prog[i].nsweeps;
-    while (k < prog.size() && (int)sor.size() < sfl::kMaxChain) {
-        bool ok = true;
-        for (size_t r = 0; r < peers.size(); ++r) {
-            const sfl_plan_step &st = progs[r][k];
-            ok = ok && st.kind == SFL_STEP_SOR && !st.from_zero && st.first_colour == 0 && st.nsweeps == ns && st.g_end > st.g_begin;
-        }
-        if (!ok) break;
-        sor.push_back(k++);
-        if (k < prog.size() && prog[k].kind == SFL_STEP_EXCHANGE && prog[k].field == SFL_FIELD_PRESSURE)
-            xch.push_back((long)k++);
-        else
-            xch.push_back(-1);
-    }
-    const int n = (int)sor.size();
-    if (n < 2) return SFL_OK;
-    for (sfl_context *c : peers)
-        if (!sfl::sor_chain_supported(c->p, c->p_alt, c->div, c->geom, ns)) return SFL_OK;
-    // two waves per SIMD for all chains together: room for the exchange stream's kernels beside them, and the occupancy the
-    // chain runs best at -- a thin slab's tiling has two tiles per SIMD; the slabs that touch the domain's boundary have three,
-    // and their chains do better with two waves per SIMD that take a second tile (0.398 ms) than with three (0.444)
-    int dev = 0, cus = 256;
-    SFL_TRY(use_device(peers[0]));
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int budget = cus * 8 / (int)peers.size();
-    if (peers[0]->opt_sor_chain >= 8 && peers[0]->opt_sor_chain < budget) budget = peers[0]->opt_sor_chain;
-    budget -= budget % 4;
-    // Side by side means a hardware queue each, for the compute stream, the exchange stream and every side stream; the runtime
-    // folds its streams onto GPU_MAX_HW_QUEUES (default 4) of them in turn.  Two virtual ranks fit the default; three when the
-    // process was started with more queues (tests/conftest.py does).  Folded streams are not a hang but a reported time-out.
-    static const int side_chains = [] {
-        const char *q = getenv("GPU_MAX_HW_QUEUES");
-        return q && atoi(q) >= 6 ? Group::kSideChains : 1;
-    }();
-    if (budget < 8 || (int)peers.size() > 1 + side_chains || (peers.size() > 1 && !peers[0]->group)) return SFL_OK;
-    for (sfl_context *c : peers) SFL_TRY(ensure_chain_words(c));   // (zeroed on the compute stream: before the event below)
-    if (peers.size() > 1) HIP_TRY(hipEventRecord(o.ready, o.compute));   // the side streams start behind what is queued so far
-
-    std::vector<std::vector<int>> senders(peers.size(), std::vector<int>(sfl::kMaxChain, 0));
-    bool fl_out = *flagged;
-    for (size_t r = 0; r < peers.size(); ++r) {
-        sfl_context *c = peers[r];
-        sfl::ChainStep steps[sfl::kMaxChain];
-        int epoch = c->arrival_epoch;   // the value the arrival count reaches with the exchanges issued so far
-        bool fl = *flagged;
-        SentBand b = (*bands)[r];
-        for (int q = 0; q < n; ++q) {
-            const sfl_plan_step &st = progs[r][sor[q]];
-            sfl::ChainStep &cs = steps[q];
-            cs.g_begin = st.g_begin;
-            cs.g_end = st.g_end;
-            cs.sweep = c->local_cells() >= kAlternateSweepCells ? c->last_launches + q : 0;
-            cs.hw = arrival_wait(c);
-            cs.hw.epoch = epoch;
-            if (!fl) cs.hw.flag = nullptr;
-            ++b.age;
-            cs.guard_flag = b.valid && b.age == 2 ? c->d_arrival : nullptr;
-            cs.guard_epoch = b.epoch;
-            cs.guard_lo_end = b.lo_end;
-            cs.guard_hi_begin = b.hi_begin;
-            fl = false;
-            if (xch[q] >= 0) {
-                const sfl_plan_step &x = progs[r][xch[q]];
-                cs.hw.done = c->d_done;
-                cs.hw.send_lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
-                cs.hw.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
-                ++epoch;
-                fl = true;
-                b.valid = true;
-                b.epoch = epoch;
-                b.lo_end = cs.hw.send_lo_end;
-                b.hi_begin = cs.hw.send_hi_begin;
-                b.age = 0;
-            }
-        }
-        hipStream_t on = c->stream;
-        if (r > 0) {
-            on = c->group->chain_stream[r - 1];
-            HIP_TRY(hipStreamWaitEvent(on, o.ready, 0));
-        }
-        bool launched = false;
-        HIP_TRY(sfl::launch_sor_chain(on, c->p, c->p_alt, c->div, c->geom, steps, n, ns, prm, c->opt_sor_rows, c->d_chain,
-                                      c->chain_words, c->chain_epoch, c->d_arrival + 1, budget, senders[r].data(),
-                                      c->opt_sor_chain < 0 ? cus * 13 : 0, &launched));
-        if (!launched) return SFL_OK;   // (automatic mode: thin slabs only; first context: nothing has been changed yet)
-        if (r > 0) HIP_TRY(hipEventRecord(c->group->ev_chain[r - 1], on));
-        c->chain_epoch += n + 1;
-        c->last_launches += n;
-        c->last_chained += n;
-        (*bands)[r] = b;
-        fl_out = fl;
-    }
-    for (size_t r = 1; r < peers.size(); ++r) HIP_TRY(hipStreamWaitEvent(o.compute, peers[r]->group->ev_chain[r - 1], 0));
-    for (int q = 0; q < n; ++q) {
-        for (sfl_context *c : peers) std::swap(c->p, c->p_alt);   // c->p = what superstep q writes: the message's source
-        for (size_t r = 0; r < peers.size(); ++r) peers[r]->done_target += senders[r][q];
-        if (xch[q] < 0) continue;
-        const sfl_plan_step &x = prog[xch[q]];
-        SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
-    }
-    *flagged = fl_out;
-    *next = k;
-    return SFL_OK;
-}
-
-// Exchanges IN TIME (slab_plan.cpp kernel 3; SFL_OPT_SOR_ARRIVAL): the halo of a superstep is sent after the launch that
+// Exchanges IN TIME (slab_plan.cpp kernel 3; SFL_OPT_EXCHANGE_SCHEDULE = 3): the halo of a superstep is sent after the launch that
 // produces it, as in the textbook -- but nothing waits for a whole launch any more.  The launch in front of an exchange
 // marks the tiles whose rows the message carries as SENDERS (top priority; each counts itself once its rows are written
 // back); the exchange stream waits for that count, not for the launch, so the message leaves while the rest of the launch
@@ -511,8 +328,6 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
                         const std::vector<std::vector<sfl_plan_step>> &progs, const sfl::SorParams &prm, const Overlap &o)
 {
     bool flagged = false;   // the next launch's cut-adjacent tiles wait for the arrival count
-    std::vector<SentBand> bands(peers.size());   // the last p message's source rows, per context (chained launches)
-    bool chain_refused = false;
     const size_t n = progs[0].size();
     for (size_t i = 0; i < n; ++i) {
         const sfl_plan_step &st0 = progs[0][i];
@@ -521,18 +336,6 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             flagged = true;
             continue;
         }
-        // automatic (-1): a context with a transport of its own (RCCL, the emulated rank) on slabs thin enough that every tile is
-        // resident at two waves per SIMD; virtual ranks (a test transport) only when asked to
-        if ((ctx->opt_sor_chain > 0 || (ctx->opt_sor_chain < 0 && !ctx->group && !chain_refused)) && !st0.from_zero) {
-            size_t next = i;
-            SFL_TRY(chain_in_time(peers, progs, i, prm, o, &flagged, &bands, &next));
-            if (next > i) {
-                i = next - 1;
-                continue;
-            }
-            chain_refused = true;   // decided once per solve: the first attempt holds the widest row ranges
-        }
-        for (SentBand &b : bands) ++b.age;
         const bool sends = i + 1 < n && progs[0][i + 1].kind == SFL_STEP_EXCHANGE && progs[0][i + 1].field == SFL_FIELD_PRESSURE;
         for (size_t k = 0; k < peers.size(); ++k) {
             sfl_context *c = peers[k];
@@ -557,14 +360,6 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
             const sfl_plan_step &x = progs[0][i + 1];
             SFL_TRY(exchange(peers, SFL_FIELD_PRESSURE, x.rows, o.xstream, x.g_begin, true, true));
             flagged = true;
-            for (size_t k = 0; k < peers.size(); ++k) {
-                const sfl_context *c = peers[k];
-                bands[k].valid = true;
-                bands[k].epoch = c->arrival_epoch;
-                bands[k].lo_end = c->rank > 0 ? c->g0 + x.g_begin + x.rows : -(1 << 30);
-                bands[k].hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
-                bands[k].age = 0;
-            }
             ++i;   // the exchange step has been issued
         }
     }
@@ -572,7 +367,7 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
 }
 
 // EARLY exchanges behind cross-stream events (slab_plan.cpp kernel 2 with halo >= 2 x fuse: every automatic
-// configuration; SFL_OPT_SOR_ARRIVAL = 0, and the default of a transport whose peers are other processes).  The ghost rows
+// configuration; SFL_OPT_EXCHANGE_SCHEDULE = 2, and the default of a transport whose peers are other processes).  The ghost rows
 // are still valid as deep as the next launch needs for the OWNED rows when the halo of the following superstep is sent:
 //   compute stream    that launch, owned rows only, whole -- no piece of it waits for the wire;
 //   exchange stream   the message (rows beyond that depth), then the same launch's passes on the ghost rows it feeds
@@ -668,7 +463,7 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
         progs.push_back(sfl::plan_poisson(c->gdim_y, c->nranks, c->rank, iters, fuse, kernel == 2 && in_time ? 3 : kernel, halo,
                                           ctx->solve_tail));
         c->last_halo = kernel == 2 && c->nranks > 1 ? halo : 0;
-        c->last_launches = c->last_exchanges = c->last_chained = 0;
+        c->last_launches = c->last_exchanges = 0;
         c->p_ghost_valid = 0;
         c->last_fuse = kernel == 1 ? 1 : fuse;
     }
@@ -694,9 +489,6 @@ int run_poisson(sfl_context *ctx, float dx, int iters, float omega)
             const sfl_plan_step &st0 = progs[0][i];
             if (st0.kind == SFL_STEP_EXCHANGE) {
                 SFL_TRY(exchange_inline(ctx, peers, st0.field, st0.rows, st0.g_begin));
-            } else if (const int n = chainable_steps(ctx, progs[0], i, false)) {   // same program shape on every peer
-                for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_chain(peers[k], progs[k], i, n, prm));
-                i += n - 1;
             } else {
                 for (size_t k = 0; k < peers.size(); ++k) SFL_TRY(exec_sor_step(peers[k], progs[k][i], prm));
             }

@@ -70,7 +70,7 @@ struct WaveTrace {
 #define SFL_PROBE_NO_EDGE 0  // diagnostic builds only: every tile takes the interior path (wrong results at the walls)
 #endif
 #ifndef SFL_SOR_TRACE
-// The SFL_PROBE_* / SFL_CHAIN_* switches compute WRONG results (or change cache policies the protocol relies on); they exist for
+// The SFL_PROBE_* switches compute WRONG results; they exist for
 // tools/sor_clock_probe.hip, which includes this file with SFL_SOR_TRACE defined.  A product library never sees them set:
 // `make EXTRA_FLAGS=-DSFL_PROBE_NO_LOAD=1` stops here.
 #ifdef SFL_PROBE_COOP
@@ -397,8 +397,6 @@ hipError_t launch_variant(hipStream_t s, float *p_out, const float *p_in, const 
     return hipGetLastError();
 }
 
-#include "sor_chain.h"
-
 template <class B, int NS, bool ZERO_IN>
 hipError_t launch_dx(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g,
                      SorRows rows, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders)
@@ -425,13 +423,13 @@ hipError_t launch_lane(hipStream_t s, float *p_out, const float *p_in, const flo
     if (can2v) {
         // written through when sender tiles publish rows of this launch while it runs (see Lane2)
         if (wait && wait->done)
-            return launch_dx<Lane2<NS, true, ZERO_IN, 16, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+            return launch_dx<Lane2<NS, true, ZERO_IN, 16, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
         // non-temporal stores once the slab's arrays no longer fit the caches
         if ((size_t)g.lrows * (size_t)g.dim_x >= kNtStoreCells)
-            return launch_dx<Lane2<NS, true, ZERO_IN, 2, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
-        return launch_dx<Lane2<NS, true, ZERO_IN, 0, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+            return launch_dx<Lane2<NS, true, ZERO_IN, 2, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+        return launch_dx<Lane2<NS, true, ZERO_IN, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
     }
-    return launch_dx<Lane2<NS, false, ZERO_IN, 0, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
+    return launch_dx<Lane2<NS, false, ZERO_IN, 0, FOLD>, NS, ZERO_IN>(s, p_out, p_in, d, g, rows, prm, rows_per_chunk, sweep, wait, senders);
 }
 
 template <int NS, bool FOLD>
@@ -500,69 +498,6 @@ SFL_DEFINE_NS(14)
 #endif
 #if SFL_NS_GROUP == 5 || SFL_NS_GROUP == -1
 SFL_DEFINE_NS(16)
-#endif
-
-// The chained launch: its kernels live in translation units of their own (SFL_NS_GROUP 6: fuse 8 and 10, 7: fuse 12 and 16).
-#define SFL_CHAIN_ARGS                                                                                                  \
-    hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps, SorParams prm,   \
-        int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out, int max_waves, int *senders,        \
-        int tiles_at_most, bool *launched
-#define SFL_DEFINE_CHAIN_PART(N, P, DX1)                                                                                \
-    hipError_t launch_sor_chain_ns##N##_p##P(SFL_CHAIN_ARGS)                                                            \
-    {                                                                                                                  \
-        return launch_chain_variant<Lane2<N, true, false, SFL_CHAIN_ST, SFL_CHAIN_LD>, N, DX1>(s, pa, pb, d, g, steps, n_steps, prm,        \
-                                                                           rows_per_chunk, flags, flag_words, epoch,   \
-                                                                           timed_out, max_waves, senders,              \
-                                                                           tiles_at_most, launched);                   \
-    }
-#if SFL_DX_PART == 0
-#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 0, true)
-#elif SFL_DX_PART == 1
-#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 1, false)
-#else
-#define SFL_DEFINE_CHAIN(N) SFL_DEFINE_CHAIN_PART(N, 0, true) SFL_DEFINE_CHAIN_PART(N, 1, false)
-#endif
-#define SFL_DECLARE_CHAIN(N)                                  \
-    hipError_t launch_sor_chain_ns##N##_p0(SFL_CHAIN_ARGS);   \
-    hipError_t launch_sor_chain_ns##N##_p1(SFL_CHAIN_ARGS);
-SFL_DECLARE_CHAIN(8) SFL_DECLARE_CHAIN(10) SFL_DECLARE_CHAIN(12) SFL_DECLARE_CHAIN(16)
-#if (SFL_NS_GROUP == 6 || SFL_NS_GROUP == -1) && SFL_FOLD_PART != 1
-SFL_DEFINE_CHAIN(8) SFL_DEFINE_CHAIN(10)
-#endif
-#if (SFL_NS_GROUP == 7 || SFL_NS_GROUP == -1) && SFL_FOLD_PART != 1
-SFL_DEFINE_CHAIN(12) SFL_DEFINE_CHAIN(16)
-#endif
-
-#if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1 && SFL_FOLD_PART != 1
-bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps)
-{
-    const uintptr_t all = reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(d);
-    return (nsweeps == 8 || nsweeps == 10 || nsweeps == 12 || nsweeps == 16) && g.dim_x % 2 == 0 && (all & 7) == 0 &&
-           pa != nullptr && pb != nullptr && pa != pb && d != nullptr;
-}
-
-hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps,
-                            int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch,
-                            int *timed_out, int max_waves, int *senders, int tiles_at_most, bool *launched)
-{
-    if (launched) *launched = false;
-    if (n_steps < 1 || n_steps > kMaxChain || !sor_chain_supported(pa, pb, d, g, nsweeps) || flags == nullptr || timed_out == nullptr)
-        return hipErrorInvalidValue;
-    for (int i = 0; i < n_steps; ++i)
-        if (steps[i].g_end <= steps[i].g_begin) return hipErrorInvalidValue;
-    const bool dx1 = prm.dx == 1.0f;
-#define SFL_CASE(N)                                                                                                        \
-    case N:                                                                                                                \
-        return dx1 ? launch_sor_chain_ns##N##_p0(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
-                                                 epoch, timed_out, max_waves, senders, tiles_at_most, launched)            \
-                   : launch_sor_chain_ns##N##_p1(s, pa, pb, d, g, steps, n_steps, prm, rows_per_chunk, flags, flag_words,   \
-                                                 epoch, timed_out, max_waves, senders, tiles_at_most, launched);
-    switch (nsweeps) {
-        SFL_CASE(8) SFL_CASE(10) SFL_CASE(12) SFL_CASE(16)
-    }
-#undef SFL_CASE
-    return hipErrorInvalidValue;
-}
 #endif
 
 #if (SFL_NS_GROUP == 0 || SFL_NS_GROUP == -1) && SFL_DX_PART != 1 && SFL_FOLD_PART != 1

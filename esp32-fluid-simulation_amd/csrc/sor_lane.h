@@ -143,11 +143,9 @@ struct WaveCommon {
 // while the launch is still running: with plain stores every sender would have to write back its XCD's whole L2 first
 // (buffer_wbl2: the launch took 48 instead of 24 us), written-through rows only have to be waited for (8192 x 1024: +0.5 %
 // for the launch, profiles/r04_experiments_without_gain.txt 3).
-// LD = cache policy of the p loads (VEC only): 0 plain; 16 = sc1, past the CU's L1 -- the chained launch (sor_chain_kernel), whose
-// tiles read rows that other CUs stored (written-through) while the launch is running.
 // FOLD = the interior relaxation's one product by -0.25f * omega (SFL_OPT_SOR_FOLD = 1; sor_stream_core.h relax); false: the
 // reference's two products, its bits on every input.
-template <int NS, bool VEC, bool ZERO_IN, int ST = 0, int LD = 0, bool FOLD = false>
+template <int NS, bool VEC, bool ZERO_IN, int ST = 0, bool FOLD = false>
 struct Lane2 : WaveCommon {
     using V = float;
     using M = bool;
@@ -222,7 +220,7 @@ struct Lane2 : WaveCommon {
         }
         if (!ZERO_IN) {
             if (VEC) {
-                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, SFL_PROBE_P_LOAD_AUX ? SFL_PROBE_P_LOAD_AUX : LD));
+                const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs_p, off_a, soff, SFL_PROBE_P_LOAD_AUX));
                 pa = q.x;
                 pb = q.y;
             } else {

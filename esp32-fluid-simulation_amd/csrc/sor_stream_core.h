@@ -494,9 +494,7 @@ SFL_HD TileRect tile_rect(const Tiling &t, int tile, int rot_c = 0, int rot_e = 
     return r;
 }
 
-// ---- which tiles of ANOTHER tiling of the same columns does a row range touch? (chained supersteps: sor_fused.hip) ----
-// Strips are the same in every tiling of a domain at one fuse depth; chunks are not (the row range of a slab's launches
-// shrinks and grows with the validity of its ghost rows).  strip_is_inner / chunk_of_row / tile_index invert tile_rect.
+// ---- strip_is_inner / chunk_of_row / tile_index invert tile_rect (the launcher's dispatch order: sor_fused.hip launch_variant) ----
 SFL_HD bool strip_is_inner(const Tiling &t, int strip) { return strip >= 1 && strip <= t.n_inner; }
 
 // chunk of `strip` whose output rows hold row r (g_begin <= r < g_end)
@@ -513,18 +511,6 @@ SFL_HD int tile_index(const Tiling &t, int strip, int chunk)
 {
     if (strip_is_inner(t, strip)) return chunk * t.n_inner + (strip - 1);
     return t.n_inner * t.n_chunks + (strip == 0 ? 0 : strip - t.n_inner) * t.n_chunks_edge + chunk;
-}
-
-// chunks [*c0, *c1] of `strip` whose output rows intersect rows [lo, hi); false: none
-SFL_HD bool chunks_touching(const Tiling &t, int strip, int lo, int hi, int *c0, int *c1)
-{
-    if (strip < 0 || strip >= t.n_strips || t.n_tiles == 0) return false;
-    if (lo < t.g_begin) lo = t.g_begin;
-    if (hi > t.g_end) hi = t.g_end;
-    if (hi <= lo) return false;
-    *c0 = chunk_of_row(t, strip, lo);
-    *c1 = chunk_of_row(t, strip, hi - 1);
-    return true;
 }
 
 // may the tile be streamed top-down?  (the RING rows of slack the pipeline needs beyond its last

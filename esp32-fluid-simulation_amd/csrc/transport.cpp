@@ -48,7 +48,7 @@ public:
     {
         // Real peers: a launch that waits inside the kernel for a message of another process is only as safe as that
         // process is punctual, and the scheme has never run on more than one GPU (tools/first_multi_gpu.sh): early
-        // exchanges behind events unless SFL_OPT_SOR_ARRIVAL = 1 asks for it.  Talking to itself the rank is its own peer.
+        // exchanges behind events unless SFL_OPT_EXCHANGE_SCHEDULE = 3 asks for it.  Talking to itself the rank is its own peer.
         return self;
     }
     bool separate_processes() const override { return !self; }
@@ -136,10 +136,6 @@ Rccl *rccl_of(const sfl_context *c) { return c->transport ? dynamic_cast<Rccl *>
 // ---- the group of virtual ranks ---------------------------------------------------------------------------------------
 Group::~Group()
 {
-    for (int k = 0; k < kSideChains; ++k) {
-        if (ev_chain[k]) (void)hipEventDestroy(ev_chain[k]);
-        if (chain_stream[k]) (void)hipStreamDestroy(chain_stream[k]);
-    }
     if (ev_ready) (void)hipEventDestroy(ev_ready);
     if (ev_arrived) (void)hipEventDestroy(ev_arrived);
     if (xstream) (void)hipStreamDestroy(xstream);
@@ -217,7 +213,6 @@ int exchange(const std::vector<sfl_context *> &peers, int field, int rows, hipSt
         }
     SFL_TRY(t->move(peers, HaloBands{field, rows, skip}, on));
     // every message before any signal: a slab's arrival count then also says that its neighbours have READ what it sent
-    // (the chained launch's guard, kernels.h ChainStep::guard_flag, relies on that)
     if (in_time)
         for (sfl_context *c : peers) {
             SFL_TRY(use_device(c));
@@ -376,18 +371,22 @@ int measure_exchange(sfl_context *ctx)
     const int deepest = std::min(kLegacySorHalo, min_owned_rows(ctx));
     const int rows_a = std::max(1, deepest / 8), rows_b = deepest;
     constexpr int kReps = 20;
+    Overlap o;
+    SFL_TRY(overlap_of(ctx, &o));   // (without an exchange stream there is nothing to reduce on either)
+    SFL_TRY(use_device(ctx));
+    // from here on a local failure is carried to the reduction at the end instead of returned (see there; a rank that cannot even
+    // start its exchanges leaves its neighbours in ncclRecv all the same: RCCL has no time-out, the launcher's deadline is the net)
+    int rc = SFL_OK;
     for (sfl_context *c : peers) {
-        SFL_TRY(ensure_field(c, SFL_FIELD_PRESSURE));
+        if (rc == SFL_OK) rc = ensure_field(c, SFL_FIELD_PRESSURE);
         c->p_ghost_valid = 0;
     }
-    Overlap o;
-    SFL_TRY(overlap_of(ctx, &o));
-    SFL_TRY(use_device(ctx));
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    for (hipEvent_t &e : ev) HIP_TRY(hipEventCreate(&e));
-    int rc = SFL_OK;
+    for (hipEvent_t &e : ev)
+        if (rc == SFL_OK && hipEventCreate(&e) != hipSuccess) rc = fail(SFL_ERR_HIP, "exchange measurement: no event");
     float ms_a = 0.0f, ms_b = 0.0f;
     do {
+        if (rc != SFL_OK) break;
         const bool counted = in_time_exchanges(ctx);
         auto one = [&](int rows) {
             if (!counted) {
@@ -417,27 +416,39 @@ int measure_exchange(sfl_context *ctx)
         if (e == hipSuccess) e = hipEventElapsedTime(&ms_b, ev[1], ev[2]);
         if (e != hipSuccess) rc = fail(SFL_ERR_HIP, "exchange measurement: %s", hipGetErrorString(e));
     } while (false);
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
     for (sfl_context *c : peers) c->last_exchanges = 0;
-    SFL_TRY(rc);
-    const double us_a = ms_a * 1e3 / kReps, us_b = ms_b * 1e3 / kReps;
-    double per_row_ns = rows_b > rows_a ? (us_b - us_a) * 1e3 / (rows_b - rows_a) : 0.0;
-    if (per_row_ns < 0.0) per_row_ns = 0.0;
-    double lat = us_a - rows_a * per_row_ns * 1e-3;
-    if (lat < 1.0) lat = 1.0;
-    // (the slope is quoted per row of 8192 four-byte cells, so that grids of other widths compare)
-    int words[2] = {(int)(lat + 0.5), (int)(per_row_ns * 8192.0 / ctx->dim_x + 0.5)};
+    // A rank that failed locally still takes part in the reduction below, with a value that says so: its peers are in it, and RCCL
+    // has no time-out.  Every rank then sees the failure and returns an error from the same call.
+    constexpr int kFailed = 1 << 30;
+    const std::string why = rc != SFL_OK ? last_error() : std::string();
+    int words[2] = {kFailed, kFailed};
+    if (rc == SFL_OK) {
+        const double us_a = ms_a * 1e3 / kReps, us_b = ms_b * 1e3 / kReps;
+        double per_row_ns = rows_b > rows_a ? (us_b - us_a) * 1e3 / (rows_b - rows_a) : 0.0;
+        if (per_row_ns < 0.0) per_row_ns = 0.0;
+        double lat = us_a - rows_a * per_row_ns * 1e-3;
+        if (lat < 1.0) lat = 1.0;
+        // (the slope is quoted per row of 8192 four-byte cells, so that grids of other widths compare)
+        words[0] = (int)(lat + 0.5);
+        words[1] = (int)(per_row_ns * 8192.0 / ctx->dim_x + 0.5);
+    }
     if (reduces_on_device(ctx)) {   // the maximum over the ranks: every rank must derive the same plan from it
-        int *dev = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), sizeof words));
-        hipError_t e = hipMemcpy(dev, words, sizeof words, hipMemcpyHostToDevice);
-        int rr = e == hipSuccess ? t->allreduce_max(ctx, dev, 2, o.xstream) : fail(SFL_ERR_HIP, "exchange measurement: %s", hipGetErrorString(e));
+        int *dev = ctx->d_collective;
+        if (hipMemcpy(dev, words, sizeof words, hipMemcpyHostToDevice) != hipSuccess)
+            (void)hipMemset(dev, 0x7f, sizeof words);   // (whatever is there is reduced; a huge value reads as a failure)
+        int rr = t->allreduce_max(ctx, dev, 2, o.xstream);
         if (rr == SFL_OK && (hipStreamSynchronize(o.xstream) != hipSuccess ||
                              hipMemcpy(words, dev, sizeof words, hipMemcpyDeviceToHost) != hipSuccess))
             rr = fail(SFL_ERR_HIP, "exchange measurement: reduction over the ranks failed");
-        (void)hipFree(dev);
         SFL_TRY(rr);
     }
+    if (rc != SFL_OK) {
+        last_error() = why;
+        return rc;
+    }
+    if (words[0] >= kFailed) return fail(SFL_ERR_STATE, "exchange measurement failed on another rank of the communicator");
     for (sfl_context *c : peers) {
         c->exchange_latency_us = words[0];
         c->exchange_ns_per_row = words[1];
@@ -467,13 +478,13 @@ int sfl_comm_unique_id(void *id_out, size_t id_bytes)
 
 // Everything that must be identical on all ranks of a communicator for their programs to match: the domain,
 // the group size and every option a plan or an exchange depends on.
-constexpr int kOptionBlockInts = 17;
+constexpr int kOptionBlockInts = 16;
 static void option_block(const sfl_context *c, int *b)
 {
     const int v[kOptionBlockInts] = {SFL_ABI_VERSION, c->dim_x, c->gdim_y, c->nranks, c->opt_sor_kernel, c->opt_sor_fuse,
                                      c->opt_sor_halo, c->opt_sor_overlap, c->opt_advect_halo, c->opt_fuse_projection,
                                      c->opt_advect_kernel, c->opt_fuse_divergence, c->opt_small_grid, c->opt_sor_arrival,
-                                     c->opt_sor_chain, c->opt_sor_fold, c->streams_concurrent};   // (streams_concurrent LAST: sfl_comm_check_options)
+                                     c->opt_sor_fold, c->streams_concurrent};   // (streams_concurrent LAST: sfl_comm_check_options)
     memcpy(b, v, sizeof v);
 }
 
@@ -628,10 +639,6 @@ int sfl_group_link(sfl_context **ctxs, int n)
     // the group's streams, one behind the other: the runtime deals streams to its hardware queues in turn
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&g->xstream, hipStreamNonBlocking));
-    for (int k = 0; k < Group::kSideChains; ++k) {
-        HIP_TRY(hipStreamCreateWithFlags(&g->chain_stream[k], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&g->ev_chain[k], hipEventDisableTiming));
-    }
     for (int r = 1; r < n; ++r) {  // group-wide options: slab 0's values
         sfl_context *c = ctxs[r], *z = ctxs[0];
         c->opt_sor_kernel = z->opt_sor_kernel;
@@ -646,7 +653,6 @@ int sfl_group_link(sfl_context **ctxs, int n)
         c->opt_fuse_divergence = z->opt_fuse_divergence;
         c->opt_small_grid = z->opt_small_grid;
         c->opt_sor_arrival = z->opt_sor_arrival;
-        c->opt_sor_chain = z->opt_sor_chain;
         c->opt_halo_timeout_ms = z->opt_halo_timeout_ms;
         c->opt_sor_fold = z->opt_sor_fold;
     }

@@ -39,7 +39,7 @@ public:
     // Does an exchange issued in line with the compute stream's work still travel on the exchange stream?  (RCCL: every
     // operation of a communicator goes to one stream; the emulated rank mimics that.  A group copies on its one stream.)
     virtual bool own_stream() const { return true; }
-    // May the executor count halo arrivals on the device (SFL_OPT_SOR_ARRIVAL automatic)?  Launches then wait for a
+    // May the executor count halo arrivals on the device (SFL_OPT_EXCHANGE_SCHEDULE automatic)?  Launches then wait for a
     // message INSIDE the kernel, which is only safe where the peer that sends it cannot be arbitrarily late and where the
     // exchange stream is known to run beside the compute stream.
     virtual bool arrival_by_default() const = 0;
@@ -56,12 +56,6 @@ public:
     hipStream_t stream = nullptr;
     hipStream_t xstream = nullptr;  // in-process halo copies of a solve (see sfl_context::xstream)
     hipEvent_t ev_ready = nullptr, ev_arrived = nullptr;
-    // chained launches (SFL_OPT_SOR_CHAIN) of virtual ranks run side by side: the first on `stream`, the others here.  Created
-    // right behind `xstream`: the runtime deals streams to its hardware queues in turn, and these streams, `stream` and `xstream`
-    // must not share one (a chain that waits for a message would sit in front of the copy that carries it)
-    static constexpr int kSideChains = 2;
-    hipStream_t chain_stream[kSideChains] = {nullptr, nullptr};
-    hipEvent_t ev_chain[kSideChains] = {nullptr, nullptr};
     int streams_concurrent = -1;   // as sfl_context::streams_concurrent, for the group's pair of streams
     HaloTuner halo_tuner;          // as sfl_context::halo_tuner, for the group's solves
     ~Group() override;

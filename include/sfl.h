@@ -87,19 +87,16 @@ extern "C" {
                                      early (sfl_plan_poisson).  Auto starts from 64 rows on slabs of >= 1024 rows
                                      (32 on thinner ones) and moves to another depth when a model of the solve --
                                      redundant rows against exchanges at their MEASURED cost,
-                                     SFL_OPT_MEASURED_WIRE_US -- predicts at least 3 % (SFL_OPT_LAST_HALO reads
-                                     what a solve used)                                                    */
+                                     SFL_OPT_MEASURED_WIRE_US -- names another candidate: the first 12 solves of a
+                                     kind (same iterations, fuse depth, schedule) then run on the candidates in
+                                     turn between pairs of events, the 13th waits for them (one host
+                                     hipEventSynchronize) and keeps the fastest (SFL_OPT_LAST_HALO reads what a
+                                     solve used).  Same bits at every depth; a caller who times fewer than 13
+                                     solves of a kind times the exploration -- or sets a depth                */
 #define SFL_OPT_FUSE_PROJECTION 7 /* sfl_step only: 1 (default) = subtract_gradient is applied
                                      inside the dye-advection kernel (one pass over v), 0 = two
                                      kernels                                                     */
 
-#define SFL_OPT_SOR_OVERLAP 8     /* slabs, kernel 2: 1 (default) = the halo exchanges of a solve run on a
-                                     second stream, in one of two schedules (SFL_OPT_SOR_ARRIVAL): in time and
-                                     counted on the device, or one launch early behind events -- a superstep's
-                                     halo then travels while the owned rows of that launch are relaxed, its ghost
-                                     rows are relaxed behind the message (halo >= 2 x fuse; shallower halos and
-                                     the right-hand side's exchange are awaited in line);
-                                     0 = every launch whole, every exchange in line                     */
 #define SFL_OPT_ADVECT_KERNEL 9   /* advection, divergence and gradient kernels: 0 = auto, 1 = one
                                      thread per cell reading its neighbours / texels from memory,
                                      2 = the window of a 64 x 32-cell tile staged in LDS (auto = 2
@@ -117,52 +114,47 @@ extern "C" {
                                      back by this many microseconds on the exchange stream before its copy
                                      starts -- the latency of a real xGMI send / receive that a self-copy does
                                      not have; 0 (default) .. 10000                                   */
-#define SFL_OPT_SOR_ARRIVAL 13     /* slabs, kernel 2, with SFL_OPT_SOR_OVERLAP: -1 (default) = automatic: 1 on virtual ranks and emulated
-                                     ranks, 0 on RCCL ranks whose peers are other processes (a launch that waits inside the
-                                     kernel is only as safe as its peer is punctual; the scheme has not run on more than one
-                                     GPU yet: tools/first_multi_gpu.sh) -- and 0 wherever the context's compute and exchange
-                                     stream were found NOT to run side by side (measured once, at attach / first solve; RCCL
-                                     ranks agree on it collectively).  1 = exchanges IN TIME, counted on the device
-                                     (sfl_plan_poisson kernel 3): the halo of a superstep is exchanged after the launch that
-                                     produces it; that launch runs the tiles whose rows the message carries at the top priority,
-                                     writes through, and counts them; the message leaves on that count while the rest of the
-                                     launch is still running; the next launch is queued at once and only its tiles next to a
-                                     cut wait, INSIDE the launch, for a count of arrived messages -- no event on the compute
-                                     stream, no launch on the ghost rows, no launch split.  A wait that outlasts
-                                     SFL_OPT_HALO_TIMEOUT_MS gives up; sfl_synchronize reports it, sfl_download and the next
-                                     operator on the context fail instead of handing out / building on an invalid field.
-                                     0 = early exchanges behind cross-stream events (round 3): the halo travels one launch
-                                     early, its ghost rows are relaxed behind the message, the launch after waits whole   */
 #define SFL_OPT_STEP_SEAMS 14      /* sfl_step_n on a whole-domain context with the tile kernels: 1 (default) = between two steps
                                      subtract_gradient + dye advection of one and velocity advection + divergence of the
                                      next run as ONE kernel (the projected velocity in between is never written to memory);
                                      0 = n times sfl_step.  Same results either way                              */
-#define SFL_OPT_SOR_CHAIN 15       /* kernel 2: consecutive launches of a solve as ONE chained launch whose waves go from one
-                                     superstep to the next without a launch boundary, each tile waiting only for the tiles
-                                     around it, in-time halo exchanges inside (fuse depths 8 / 10 / 12 / 16, even dim_x).
-                                     0 (default) = one launch per superstep; 1 = wherever it can run; -1 = automatic: slabs
-                                     with a transport of their own (RCCL, the emulated rank) that are thin enough for two
-                                     waves per SIMD to hold their tiles; a value >= 8 = 1 with at most that many waves per
-                                     chain (a test aid: several tiles per wave).  Same results either way; measured -4 .. +3 %
-                                     on the emulated ranks of 8192^2 on 8 GPUs, slower on larger slabs        */
-#define SFL_OPT_LAST_CHAINED 16    /* READ ONLY: supersteps of the last solve that ran inside chained launches          */
 #define SFL_OPT_LAST_EARLY_ROWS 17 /* READ ONLY: slabs on the automatic advection halo: L > 0 when the last sfl_step kept the velocity
                                      advection of the rows further than L from both cuts that it had queued BEFORE reading the
                                      previous step's report (they need no halo; the report says whether that held); 0 = the step
                                      advected everything after the report                                            */
 
-#define SFL_OPT_HALO_TIMEOUT_MS 18  /* limit of a wait INSIDE a launch or on the exchange stream (SFL_OPT_SOR_ARRIVAL = 1, chained launches),
+#define SFL_OPT_HALO_TIMEOUT_MS 18  /* limit of a wait INSIDE a launch or on the exchange stream (SFL_OPT_EXCHANGE_SCHEDULE = 3),
                                      milliseconds: 0 (default) = the transport's own: 2 s where every party is this process
                                      (virtual ranks, emulated ranks), 300 s on RCCL ranks -- a peer process may simply be late
                                      (I/O, a garbage collection), and what used to be an event wait must not become an error */
-#define SFL_OPT_EXCHANGE_SCHEDULE 19 /* READ ONLY: how the next solve on this slab will order its halo exchanges: 0 = none to
-                                     order (whole domain, no transport, the baseline kernel), 1 = in line, 2 = one launch early
-                                     behind cross-stream events, 3 = in time, counted on the device                        */
+#define SFL_OPT_EXCHANGE_SCHEDULE 19 /* slabs, kernel 2: how a solve orders its halo exchanges -- ONE option for what rounds 2 - 5 spread over
+                                     SFL_OPT_SOR_OVERLAP (8), SFL_OPT_SOR_ARRIVAL (13) and SFL_OPT_SOR_CHAIN (15; the chained launch was
+                                     retired in round 6), whose numbers are no longer accepted.  All schedules give the same bits.
+                                     SET: 0 (default) = automatic: 3 on virtual and emulated ranks, 2 on RCCL ranks whose peers are
+                                          other processes (a launch that waits inside the kernel is only as safe as its peer is
+                                          punctual, and the scheme has not run on more than one GPU yet: tools/first_multi_gpu.sh);
+                                          2 wherever the context's compute and exchange stream were found NOT to run side by side
+                                          (measured once, at attach / first solve; RCCL ranks agree on it collectively);
+                                       1 = in line: every launch whole, every exchange awaited on the compute stream;
+                                       2 = one launch early, behind cross-stream events (round 3): a superstep's halo travels on the
+                                          exchange stream while the owned rows of that launch are relaxed, its ghost rows are relaxed
+                                          behind the message, the launch after waits whole (halo >= 2 x fuse; shallower halos and the
+                                          right-hand side's exchange are awaited in line);
+                                       3 = in time, counted on the device (sfl_plan_poisson kernel 3): the halo is exchanged after the
+                                          launch that produces it; that launch runs the tiles whose rows the message carries at the
+                                          top priority, writes through, and counts them; the message leaves on that count while the
+                                          rest of the launch is still running; the next launch is queued at once and only its tiles
+                                          next to a cut wait, INSIDE the launch, for a count of arrived messages.  A wait that outlasts
+                                          SFL_OPT_HALO_TIMEOUT_MS gives up; sfl_synchronize reports it, sfl_download and the next
+                                          operator on the context fail instead of handing out / building on an invalid field.
+                                     GET: what the next solve will do: 0 = nothing to order (whole domain, no transport, the baseline
+                                          kernel), else 1 / 2 / 3 with the automatic choice and the streams' verdict resolved        */
 #define SFL_OPT_MEASURED_WIRE_US 20  /* READ ONLY: slabs with a transport: microseconds one halo exchange of this context costs before
                                      its first byte moves (launches, protocol, wire), measured -- not assumed -- with
                                      back-to-back exchanges of p at two depths when the transport was attached (RCCL ranks:
-                                     the maximum over the ranks) or on first demand (virtual / emulated ranks: the copy, and
-                                     SFL_OPT_EMULATE_WIRE_US if set); -1 = nothing to measure.  The automatic halo depth of a
+                                     the maximum over the ranks) or in front of the first solve (virtual / emulated ranks: the
+                                     copy, and SFL_OPT_EMULATE_WIRE_US if set); -1 = nothing to measure, or not measured yet
+                                     (the query itself never measures: that is a collective of the ranks and belongs to a solve).  The automatic halo depth of a
                                      solve (SFL_OPT_SOR_HALO = 0) is chosen from it: deeper halos = fewer exchanges, more rows
                                      relaxed redundantly                                                             */
 #define SFL_OPT_LAST_HALO 21         /* READ ONLY: halo depth (rows of p per superstep) of the last solve's plan on this slab  */
@@ -242,7 +234,7 @@ typedef struct sfl_plan_step {
 SFL_API int sfl_plan_poisson(int dim_y, int nranks, int rank, int iters, int fuse, int kernel,
                              int halo, sfl_plan_step *steps, int cap, int *n_steps);
 /* kernel = 3: kernel 2's launches with IN-TIME exchanges at every halo depth -- never early: the exchange of a superstep
- * follows the launch that produces its rows (SFL_OPT_SOR_ARRIVAL; with a tail every superstep holds halo - tail passes and its
+ * follows the launch that produces its rows (SFL_OPT_EXCHANGE_SCHEDULE = 3; with a tail every superstep holds halo - tail passes and its
  * exchange skips the `tail` ghost rows the launch before left exact).                                                    */
 /* The same with a TAIL: `tail` ghost rows of p are still exact when the solve ends (every launch of an
  * early-exchange plan then extends that much further into the ghost rows; ignored -- as 0 -- by the other

@@ -10,9 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-# (The suite runs under the runtime's own defaults -- GPU_MAX_HW_QUEUES = 4 in particular, as the product does.  The one
-# configuration that needs more, three chained launches side by side, starts a process of its own:
-# tests/test_gpu_parity.py::test_chained_launch_across_halo_exchanges.)
+# (The suite runs under the runtime's own defaults -- GPU_MAX_HW_QUEUES = 4 in particular, as the product does.)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

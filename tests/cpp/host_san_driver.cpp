@@ -189,6 +189,16 @@ static void bad_arguments()
         CHECK(sfl_set_option(ctx, SFL_OPT_SOR_HALO, 161) == SFL_ERR_INVALID && sfl_set_option(ctx, SFL_OPT_ADVECT_HALO, 65) == SFL_ERR_INVALID, "halo limits");
         CHECK(sfl_set_option(ctx, SFL_OPT_TRANSPORT, 1) == SFL_ERR_INVALID && sfl_set_option(ctx, SFL_OPT_LAST_HALO, 1) == SFL_ERR_INVALID, "read-only options");
         CHECK(sfl_set_option(ctx, 999, 1) == SFL_ERR_INVALID && sfl_get_option(ctx, 999, &v) == SFL_ERR_INVALID, "unknown option");
+        // round 6: one read / write option for the exchange schedule; the numbers of the three it replaces (and of the chained launch's
+        // read-out) are refused; the opt-in arithmetic reads back
+        CHECK(sfl_set_option(ctx, SFL_OPT_EXCHANGE_SCHEDULE, 4) == SFL_ERR_INVALID && sfl_set_option(ctx, SFL_OPT_EXCHANGE_SCHEDULE, -1) == SFL_ERR_INVALID, "schedule 4 / -1");
+        for (int sch = 3; sch >= 0; --sch) CHECK(sfl_set_option(ctx, SFL_OPT_EXCHANGE_SCHEDULE, sch) == SFL_OK, "schedule %d", sch);
+        CHECK(sfl_get_option(ctx, SFL_OPT_EXCHANGE_SCHEDULE, &v) == SFL_OK && v == 0, "a whole-domain context has nothing to order");
+        for (int retired : {8, 13, 15, 16})
+            CHECK(sfl_set_option(ctx, retired, 1) == SFL_ERR_INVALID && sfl_get_option(ctx, retired, &v) == SFL_ERR_INVALID, "retired option %d", retired);
+        CHECK(sfl_get_option(ctx, SFL_OPT_SOR_FOLD, &v) == SFL_OK && v == 0, "the reference's two products are the default");
+        CHECK(sfl_set_option(ctx, SFL_OPT_SOR_FOLD, 1) == SFL_OK && sfl_get_option(ctx, SFL_OPT_SOR_FOLD, &v) == SFL_OK && v == 1, "fold reads back");
+        CHECK(sfl_get_option(ctx, SFL_OPT_MEASURED_WIRE_US, &v) == SFL_OK && v == -1, "nothing to measure on a whole domain, and the query measures nothing");
         CHECK(sfl_get_option(ctx, SFL_OPT_SOR_FUSE, nullptr) == SFL_ERR_INVALID, "NULL value");
         CHECK(sfl_destroy(ctx) == SFL_OK, "destroy");
     } else {

@@ -20,8 +20,6 @@ hipError_t launch_divergence_tiled(hipStream_t s, float *div, const float *v, Sl
 hipError_t launch_gradient_tiled(hipStream_t s, float *v, const float *p, Slab g, int g_begin, int g_end, float two_dx_inv) { return hipErrorNoDevice; }
 hipError_t launch_sor_half_sweep(hipStream_t s, float *p, const float *d, Slab g, int g_begin, int g_end, int colour, SorParams prm) { return hipErrorNoDevice; }
 hipError_t launch_sor_fused(hipStream_t s, float *p_out, const float *p_in, const float *d, Slab g, SorRows rows, int nsweeps, int first_colour, SorParams prm, int rows_per_chunk, int sweep, const HaloWait *wait, int *senders) { return hipErrorNoDevice; }
-bool sor_chain_supported(const float *pa, const float *pb, const float *d, Slab g, int nsweeps) { return false; }
-hipError_t launch_sor_chain(hipStream_t s, float *pa, float *pb, const float *d, Slab g, const ChainStep *steps, int n_steps, int nsweeps, SorParams prm, int rows_per_chunk, int *flags, int flag_words, int epoch, int *timed_out, int max_waves, int *senders, int tiles_at_most, bool *launched) { return hipErrorNoDevice; }
 hipError_t launch_signal_arrival(hipStream_t s, int *flag, int value) { return hipErrorNoDevice; }
 hipError_t launch_wait_count(hipStream_t s, const int *count, int target, int *timed_out, int timeout_us) { return hipErrorNoDevice; }
 bool small_grid_fits(int dim_x, int dim_y) { return false; }

@@ -335,48 +335,6 @@ emu_tiling_cover(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, in
     return t.n_tiles;
 }
 
-// Chained supersteps: the tiles of tiling A (the previous superstep) that a tile of tiling B has to wait for are those whose
-// output rectangle intersects B's tile grown by `reach` rows and one strip to each side.  Compares the product's inverse
-// arithmetic (chunks_touching / tile_index) with a brute-force search over A's tiles; returns the number of (tile, dependency)
-// pairs, or -1 at the first difference.
-extern "C" __attribute__((visibility("default"))) int
-emu_tiling_deps(int ns, int tile_cols, int col_align, int dim_x, int gdim_y, int a_begin, int a_end, int a_rpc,
-                int b_begin, int b_end, int b_rpc, int balance, int reach)
-{
-    using namespace sfl::sor;
-    const Tiling a = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, a_begin, a_end, a_rpc, balance, 1);
-    const Tiling b = make_tiling(ns, tile_cols, col_align, dim_x, gdim_y, b_begin, b_end, b_rpc, balance, 2);
-    int pairs = 0;
-    std::vector<char> want(a.n_tiles), got(a.n_tiles);
-    for (int tile = 0; tile < a.n_tiles; ++tile) {   // the inverse maps are inverses
-        const TileRect r = tile_rect(a, tile);
-        if (tile_index(a, r.strip, chunk_of_row(a, r.strip, r.r0)) != tile) return -1;
-        if (tile_index(a, r.strip, chunk_of_row(a, r.strip, r.r1 - 1)) != tile) return -1;
-    }
-    for (int tile = 0; tile < b.n_tiles; ++tile) {
-        const TileRect r = tile_rect(b, tile);
-        const int lo = r.r0 - reach, hi = r.r1 + reach;
-        std::fill(want.begin(), want.end(), 0);
-        std::fill(got.begin(), got.end(), 0);
-        for (int k = 0; k < a.n_tiles; ++k) {
-            const TileRect q = tile_rect(a, k);
-            want[k] = q.strip >= r.strip - 1 && q.strip <= r.strip + 1 && q.r0 < hi && q.r1 > lo;
-        }
-        for (int ds = -1; ds <= 1; ++ds) {
-            int c0, c1;
-            if (!chunks_touching(a, r.strip + ds, lo, hi, &c0, &c1)) continue;
-            for (int c = c0; c <= c1; ++c) {
-                const int k = tile_index(a, r.strip + ds, c);
-                if (k < 0 || k >= a.n_tiles || got[k]) return -1;
-                got[k] = 1;
-                ++pairs;
-            }
-        }
-        if (want != got) return -1;
-    }
-    return pairs;
-}
-
 // Dispatch order (sor::tile_rect's rotation): for any rotation of the chunk numbers of the inner strips (rot_c) and of the
 // boundary strips (rot_e) the map position -> (strip, output rows) must visit every tile of the tiling exactly once, and the
 // first fc x n_inner positions must be the chunks [rot_c, rot_c + fc) of the inner strips.  Returns n_tiles, or -1.

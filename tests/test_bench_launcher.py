@@ -61,8 +61,10 @@ def test_bench_self_launch_as_typed():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode == 0, r.stderr
     out = _json_line(r.stdout)
-    assert out == {"dry_run": True, "n_gpus": 3, "max_rank": 2.0, "mode": "in-time", "tokens_agree": True, "ranks": [0, 1, 2],
-                   "devices": [0, 1, 2], "rccl_host_ids": [None, None, None], "exchange_mode": "in-time", "fallback_from": []}
+    # the headline is the LIBRARY'S OWN schedule (no flag); the in-time schedule runs afterwards as a labelled experiment
+    assert out == {"dry_run": True, "n_gpus": 3, "max_rank": 2.0, "mode": "library default", "tokens_agree": True, "ranks": [0, 1, 2],
+                   "devices": [0, 1, 2], "rccl_host_ids": [None, None, None], "exchange_mode": "library default", "fallback_from": [],
+                   "in_time_experiment": {"dry_run": True, "mode": "in-time"}}
 
 
 def test_share_device_gives_every_rank_the_device_and_a_host_id_of_its_own():
@@ -128,64 +130,110 @@ def test_self_launcher_deadline():
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
 
 
-# ---- round 5: a chain of exchange schedules, fresh rank processes per attempt ------------------------
+# ---- rounds 5 / 6: the headline is the library's default schedule; fresh rank processes per attempt; in line as the fallback; the
+# in-time schedule as a separately labelled experiment behind a successful headline
 def _clean_env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SFL_BENCH_WORKER")}
     env.update(extra)
     return env
 
 
+def _bench(*argv, timeout=300, **env):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True,
+                          timeout=timeout, env=_clean_env(**env))
+
+
 def test_one_gpu_line_has_no_launcher_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True,
-                       text=True, timeout=120, env=_clean_env())
+    r = _bench("--gpus", "1", "--dry-run", timeout=120)
     assert r.returncode == 0, r.stderr
     out = _json_line(r.stdout)
-    assert "exchange_mode" not in out and "fallback_from" not in out and out["mode"] == "library default"
+    assert "exchange_mode" not in out and "fallback_from" not in out and "in_time_experiment" not in out and out["mode"] == "library default"
 
 
-def test_self_launcher_falls_back_to_the_next_schedule():
-    """The default schedule (exchanges in time) fails on a rank: fresh ranks are started with early exchanges behind events,
-    the line says which schedule produced it and why the first did not."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True,
-                       text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time"))
+def test_headline_is_the_library_default_and_the_experiment_rides_along():
+    """the first multi-GPU line must show what a caller of sfl_poisson_solve gets.  Both keys in ONE line."""
+    r = _bench("--gpus", "2", "--dry-run")
     assert r.returncode == 0, r.stderr[-2000:]
     out = _json_line(r.stdout)
-    assert out["exchange_mode"] == "by-event" and out["mode"] == "by-event" and out["n_gpus"] == 3
-    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
+    assert out["exchange_mode"] == "library default" and out["mode"] == "library default" and out["fallback_from"] == []
+    assert out["in_time_experiment"] == {"dry_run": True, "mode": "in-time"}
+    r = _bench("--gpus", "2", "--dry-run", "--no-experiment")
+    assert r.returncode == 0 and "in_time_experiment" not in _json_line(r.stdout)
+
+
+@pytest.mark.parametrize("broken", ["fail", "hang"])
+def test_a_failing_experiment_costs_the_headline_nothing(broken):
+    env = {"SFL_BENCH_TEST_FAIL_MODES": "in-time"} if broken == "fail" else {"SFL_BENCH_TEST_HANG_MODES": "in-time"}
+    r = _bench("--gpus", "2", "--dry-run", "--launch-timeout", "4", **env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "library default" and out["fallback_from"] == []
+    assert ("made to fail by the test" if broken == "fail" else "no result after 4 s") in out["in_time_experiment"]["failed"]
+
+
+def test_self_launcher_falls_back_to_exchanges_in_line():
+    """The library's own schedule fails on a rank: fresh ranks are started with every exchange in line, the line says which
+    schedule produced it and why the first did not; the experiment still follows the headline it can be compared with."""
+    r = _bench("--gpus", "3", "--dry-run", SFL_BENCH_TEST_FAIL_MODES="library default")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "in-line" and out["mode"] == "in-line" and out["n_gpus"] == 3
+    assert [f["mode"] for f in out["fallback_from"]] == ["library default"]
     assert "made to fail by the test" in out["fallback_from"][0]["why"]
+    assert out["in_time_experiment"] == {"dry_run": True, "mode": "in-time"}
 
 
 def test_self_launcher_falls_back_past_a_schedule_that_hangs():
     """... or never finishes: the per-attempt deadline stops its ranks, the next schedule gets fresh ones."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "4"],
-                       capture_output=True, text=True, timeout=300,
-                       env=_clean_env(SFL_BENCH_TEST_HANG_MODES="in-time", SFL_BENCH_TEST_FAIL_MODES="by-event"))
+    r = _bench("--gpus", "2", "--dry-run", "--launch-timeout", "4", "--no-experiment", SFL_BENCH_TEST_HANG_MODES="library default")
     assert r.returncode == 0, r.stderr[-2000:]
     out = _json_line(r.stdout)
     assert out["exchange_mode"] == "in-line"
-    assert [f["mode"] for f in out["fallback_from"]] == ["in-time", "by-event"]
+    assert [f["mode"] for f in out["fallback_from"]] == ["library default"]
     assert "no result after 4 s" in out["fallback_from"][0]["why"] and out["fallback_from"][0]["status"] == 124
 
 
 def test_self_launcher_reports_every_schedules_reason_when_all_fail():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
-                       text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event,in-line"))
+    r = _bench("--gpus", "2", "--dry-run", SFL_BENCH_TEST_FAIL_MODES="library default,in-line")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     tail = [l for l in r.stderr.splitlines() if "every exchange schedule failed" in l]
     assert len(tail) == 1
     reasons = json.loads(tail[0].split("failed: ", 1)[1])
-    assert [f["mode"] for f in reasons] == ["in-time", "by-event", "in-line"]
+    assert [f["mode"] for f in reasons] == ["library default", "in-line"]     # (no experiment without a headline)
     assert all("made to fail by the test" in f["why"] for f in reasons)
 
 
 def test_a_schedule_asked_for_is_the_only_one_tried():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--arrival-by-event"],
-                       capture_output=True, text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="by-event"))
+    r = _bench("--gpus", "2", "--dry-run", "--arrival-by-event", SFL_BENCH_TEST_FAIL_MODES="by-event")
     assert r.returncode != 0 and "starting fresh ranks" not in r.stderr
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-overlap"],
-                       capture_output=True, text=True, timeout=300, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event"))
-    assert r.returncode == 0 and _json_line(r.stdout)["exchange_mode"] == "in-line"
+    r = _bench("--gpus", "2", "--dry-run", "--no-overlap", SFL_BENCH_TEST_FAIL_MODES="library default,in-time")
+    out = _json_line(r.stdout)
+    assert r.returncode == 0 and out["exchange_mode"] == "in-line" and "in_time_experiment" not in out
+    r = _bench("--gpus", "2", "--dry-run", "--arrival-in-time")
+    assert r.returncode == 0 and _json_line(r.stdout)["exchange_mode"] == "in-time"
+
+
+def test_a_variant_library_travels_to_the_rank_processes():
+    """under tools/with_lib.py (SFL_WITH_LIB) the rank processes are started through with_lib.py as well."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = os.environ.pop("SFL_WITH_LIB", None)
+    try:
+        assert bench.worker_argv(["--x"])[1].endswith("bench.py")
+        os.environ["SFL_WITH_LIB"] = "/somewhere/libsfl_variant.so"
+        argv = bench.worker_argv(["--x"])
+        assert argv[1].endswith(os.path.join("tools", "with_lib.py")) and argv[2] == "/somewhere/libsfl_variant.so" and argv[3].endswith("bench.py")
+    finally:
+        os.environ.pop("SFL_WITH_LIB", None)
+        if old is not None:
+            os.environ["SFL_WITH_LIB"] = old
+
+
+def _torchrun(port, *argv, **env):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                           "--dry-run"] + list(argv), capture_output=True, text=True, timeout=600, env=_clean_env(**env))
 
 
 @pytest.mark.parametrize("broken", ["fail", "hang"])
@@ -193,23 +241,41 @@ def test_fallback_under_torch_distributed_run(broken):
     """The driver's command line: torch.distributed.run starts one bench.py per rank; each is its rank's supervisor, starts a
     fresh worker per attempt, and the supervisors agree on failing over to the next schedule together -- none of them exits
     non-zero in between (the elastic agent would end the run)."""
-    env = _clean_env(**({"SFL_BENCH_TEST_FAIL_MODES": "in-time"} if broken == "fail" else {"SFL_BENCH_TEST_HANG_MODES": "in-time"}))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29641" if broken == "fail" else "29643",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--launch-timeout", "5"],
-                       capture_output=True, text=True, timeout=600, env=env)
+    env = {"SFL_BENCH_TEST_FAIL_MODES": "library default"} if broken == "fail" else {"SFL_BENCH_TEST_HANG_MODES": "library default"}
+    r = _torchrun(29641 if broken == "fail" else 29643, "--launch-timeout", "5", **env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _json_line(r.stdout)
-    assert out["n_gpus"] == 2 and out["exchange_mode"] == "by-event" and out["tokens_agree"]
-    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
+    assert out["n_gpus"] == 2 and out["exchange_mode"] == "in-line" and out["tokens_agree"]
+    assert [f["mode"] for f in out["fallback_from"]] == ["library default"]
     assert ("made to fail by the test" if broken == "fail" else "no result after 5 s") in out["fallback_from"][0]["why"]
+    assert out["in_time_experiment"] == {"dry_run": True, "mode": "in-time"}
+
+
+def test_headline_and_experiment_under_torch_distributed_run():
+    r = _torchrun(29647)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "library default" and out["fallback_from"] == []
+    assert out["in_time_experiment"] == {"dry_run": True, "mode": "in-time"}
+    r = _torchrun(29649, "--launch-timeout", "5", SFL_BENCH_TEST_HANG_MODES="in-time")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["exchange_mode"] == "library default" and "no result after 5 s" in out["in_time_experiment"]["failed"]
 
 
 def test_all_schedules_failing_under_torch_distributed_run():
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29645",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
-                       capture_output=True, text=True, timeout=600, env=_clean_env(SFL_BENCH_TEST_FAIL_MODES="in-time,by-event,in-line"))
+    r = _torchrun(29645, SFL_BENCH_TEST_FAIL_MODES="library default,in-line")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "every exchange schedule failed" in r.stderr
+
+
+def test_the_multi_gpu_suite_fits_the_drivers_limit():
+    """on a node with 8 GPUs the one-rank-per-GPU cases un-skip on top of the one-GPU suite (~4 minutes) under
+    the driver's 1200 s limit: at most 10 of them in the default selection, configuration 5 (a 43 s reference solve) once."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    m = importlib.import_module("test_multi_gpu")
+    assert len(m.REAL_GPU_CASES) <= 10
+    assert sum(1 for c in m.REAL_GPU_CASES if c[1] == 16384) == 1
+    assert {(c[0], c[1], c[2]) for c in m.REAL_GPU_CASES} >= {(2, 8192, 80), (4, 8192, 80), (8, 8192, 80), (8, 16384, 200)}
+    assert len(m.REAL_GPU_CASES_SLOW) >= 5

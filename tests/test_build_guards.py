@@ -16,11 +16,11 @@ CSRC = os.path.join(ROOT, "esp32-fluid-simulation_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.parametrize("flag", ["-DSFL_PROBE_NO_LOAD=1", "-DSFL_PROBE_SHIFT=1", "-DSFL_PROBE_COOP=3", "-DSFL_CHAIN_ST=0"])
+@pytest.mark.parametrize("flag", ["-DSFL_PROBE_NO_LOAD=1", "-DSFL_PROBE_SHIFT=1", "-DSFL_PROBE_COOP=3"])
 def test_a_product_build_refuses_the_diagnostic_switches(flag):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    group = "6" if "CHAIN" in flag else "2"      # (the chained launch's kernels live in fuse groups 6 and 7)
+    group = "2"
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fsyntax-only", f"-DSFL_NS_GROUP={group}",
                         "-DSFL_DX_PART=0", flag, os.path.join(CSRC, "sor_fused.hip")], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0

@@ -19,7 +19,7 @@ OMEGA = np.float32(1.96)
 def plan_exchanges(sfl, dim_y, nranks, iters, fuse, halo=0, kernel=3):
     """Halo exchanges of one fused-kernel solve as the library plans it with an automatic (0) or given halo:
     counted on the program sfl_plan_poisson returns (csrc/sor_executor.cpp legacy_halo restated; the automatic depth is a timed choice: pass the solve's own).  kernel 3 = exchanges in
-    time (the default executor, SFL_OPT_SOR_ARRIVAL), 2 = early exchanges where the halo is deep enough."""
+    time (the default executor), 2 = early exchanges where the halo is deep enough."""
     rows = min(b - a for a, b in (sfl.slab_rows(dim_y, nranks, r) for r in range(nranks)))
     h = halo or (64 if rows >= 1024 else 32)      # (callers pass last_solve_info()["halo"]: the automatic depth is a measured choice)
     h = max(min(h, rows, 160), fuse)
@@ -816,12 +816,12 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
     # overlapped with the halo's arrival signalled on the device (the default: cut-adjacent tiles wait inside the
     # launch), overlapped with a cross-stream event in front of the launch, in line
     # in time, counted on the device (the default); early behind cross-stream events; in line
-    for overlap, arrival in ((1, 1), (1, 0), (0, 1)):
+    for schedule in (sfl.capi.SCHEDULE_IN_TIME, sfl.capi.SCHEDULE_BY_EVENT, sfl.capi.SCHEDULE_IN_LINE):
         slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
         try:
             sfl.Solver.link_group(slabs)
-            slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
-            slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, arrival)
+            slabs[0].set_option(sfl.capi.OPT_EXCHANGE_SCHEDULE, schedule)
+            assert slabs[-1].get_option(sfl.capi.OPT_EXCHANGE_SCHEDULE) == schedule     # group-wide, and resolved to itself
             slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
             slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
             for s in slabs:
@@ -834,13 +834,13 @@ def test_overlapped_halo_exchange_gives_the_same_bits(sfl, oracle, nranks, dim_y
         finally:
             for s in slabs:
                 s.close()
-        assert_bit_equal(got, want, f"{nranks} slabs, overlap {overlap}, arrival counted on the device {arrival}")
+        assert_bit_equal(got, want, f"{nranks} slabs, exchange schedule {schedule}")
     # (in time and in line walk the same kernel-3 program; the early program has the same launches)
     assert infos[0]["launches"] == infos[1]["launches"] == infos[2]["launches"] and all(i["exchanges"] > 0 for i in infos)
 
 
 def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
-    """SFL_OPT_SOR_ARRIVAL: exchanges in time -- the message leaves on a device-side count of the launch's sender tiles, the
+    """SFL_OPT_EXCHANGE_SCHEDULE = 3: exchanges in time -- the message leaves on a device-side count of the launch's sender tiles, the
     next launch is queued without a cross-stream event and its cut-adjacent tiles poll an arrival count and acquire.  Many solves back to back on 8 virtual ranks of a grid wide enough
     that the launches fill the chip (the polling tiles' CUs are busy and L1-warm from the previous launch, the exchange
     stream's copies and ghost-row launches run beside them), every solve's result against the oracle."""
@@ -851,9 +851,9 @@ def test_halo_arrival_inside_the_launch_under_load(sfl, oracle):
         sfl.Solver.link_group(slabs)
         slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, 10)
         slabs[0].set_option(sfl.capi.OPT_SOR_HALO, 32)     # (the automatic depth is a timed choice: this test wants its exchanges)
-        assert slabs[3].get_option(sfl.capi.OPT_SOR_ARRIVAL) == -1 and slabs[3].get_option(sfl.capi.OPT_EXCHANGE_SCHEDULE) == 3   # automatic: in time
+        assert slabs[3].get_option(sfl.capi.OPT_EXCHANGE_SCHEDULE) == 3   # automatic on virtual ranks: in time
         for rep in range(3):
-            slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, 0 if rep == 1 else 1)   # (early exchanges behind events in the middle repetition)
+            slabs[0].set_option(sfl.capi.OPT_EXCHANGE_SCHEDULE, 2 if rep == 1 else 3)   # (early exchanges behind events in the middle repetition)
             d = (rng.standard_normal((dim_y, dim_x)) * 0.1).astype(np.float32)
             for s in slabs:
                 s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
@@ -1239,77 +1239,6 @@ def test_every_fuse_depth_from_zero_and_continuing(sfl, oracle, fuse):
         assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"fuse {fuse} dx {dx}")
 
 
-@pytest.mark.parametrize("fuse", [8, 10, 12, 16])
-@pytest.mark.parametrize("dim_x,dim_y,rows", [(1500, 1100, 0), (3000, 700, 23), (258, 2000, 0), (1030, 513, 40), (8192, 1024, 0)])
-def test_chained_launch_gives_the_same_bits(sfl, oracle, fuse, dim_x, dim_y, rows):
-    """SFL_OPT_SOR_CHAIN: the launches of a solve behind the first one as ONE launch whose waves go from superstep to
-    superstep, each tile waiting only for the tiles around it (sor_chain_kernel).  Against the oracle on shapes with many
-    tiles per strip and per wave, pitches that are not whole cache lines, forced and automatic tile heights, dx = 1 and
-    dx != 1, up to seven supersteps per chain -- and the chained launch really ran."""
-    if dim_x * dim_y > 4_000_000 and fuse not in (10, 16):
-        pytest.skip("the thin share of the headline grid: the two depths it is run at")
-    _, _, d = random_fields(dim_x, dim_y, 90 + fuse)
-    for dx, launches in ((1.0, 7), (0.75, 4)):
-        iters = fuse // 2 * launches
-        with sfl.Solver(dim_x, dim_y) as s:
-            s.set_option(sfl.capi.OPT_SOR_KERNEL, 2)
-            s.set_option(sfl.capi.OPT_SOR_FUSE, fuse)
-            s.set_option(sfl.capi.OPT_SOR_ROWS, rows)
-            s.set_option(sfl.capi.OPT_SOR_CHAIN, 1 if dx == 1.0 else 64)   # (64: few waves, many tiles per wave)
-            s.upload(sfl.capi.FIELD_DIVERGENCE, d)
-            for _ in range(2):          # twice: the words of the first chain are still there for the second
-                s.poisson_solve(dx, iters, OMEGA)
-            s.synchronize()
-            info = s.last_solve_info()
-            got = s.download(sfl.capi.FIELD_PRESSURE)
-        assert info["fuse"] == fuse and info["launches"] == launches
-        assert_bit_equal(got, oracle.poisson_solve(d, dx, iters, OMEGA), f"chained, fuse {fuse} dx {dx} {dim_x}x{dim_y}")
-
-
-@pytest.mark.parametrize("nranks,dim_x,dim_y,fuse,halo,iters", [
-    (2, 1030, 700, 8, 24, 40), (3, 2048, 1500, 10, 32, 60), (2, 8192, 640, 10, 40, 45), (3, 3000, 1200, 8, 16, 36),
-    (2, 4096, 2048, 10, 0, 80), (3, 1500, 900, 12, 36, 54)])
-def test_chained_launch_across_halo_exchanges(sfl, oracle, nranks, dim_x, dim_y, fuse, halo, iters):
-    """SFL_OPT_SOR_CHAIN on slabs: the in-time halo protocol INSIDE the chained launch -- sender tiles count themselves, the
-    exchange stream copies and raises the arrival count while the chain is running, cut-adjacent tiles of the next superstep
-    poll it, and the tile that overwrites a message's source two supersteps later waits for that message.  Two and three
-    virtual ranks, whose chains run side by side on a stream each; several exchanges inside one chain; pitches that are not
-    whole cache lines; two solves back to back.  Bit for bit the undivided solve -- and the chains really ran."""
-    if nranks > 2 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 6:
-        # three chains side by side need a hardware queue each; the runtime reads GPU_MAX_HW_QUEUES when it starts, and the rest
-        # of the suite is to run under the runtime's default (4): this case runs in a process of its own with 8
-        import subprocess
-        import sys
-        case = f"tests/test_gpu_parity.py::test_chained_launch_across_halo_exchanges[{nranks}-{dim_x}-{dim_y}-{fuse}-{halo}-{iters}]"
-        r = subprocess.run([sys.executable, "-m", "pytest", case, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT,
-                           env=dict(os.environ, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and "1 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
-        return
-    _, _, d = random_fields(dim_x, dim_y, 300 + fuse + nranks)
-    want = oracle.poisson_solve(d, 1.0, iters, OMEGA)
-    slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
-    try:
-        sfl.Solver.link_group(slabs)
-        slabs[0].set_option(sfl.capi.OPT_SOR_FUSE, fuse)
-        slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo or 64)   # (0 would be a timed choice: this test wants its exchanges)
-        slabs[0].set_option(sfl.capi.OPT_SOR_CHAIN, 1)
-        assert slabs[-1].get_option(sfl.capi.OPT_SOR_CHAIN) == 1
-        for s in slabs:
-            s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
-        for _ in range(2):
-            slabs[0].poisson_solve(1.0, iters, OMEGA)
-        slabs[0].synchronize()
-        info = slabs[nranks // 2].last_solve_info()
-        chained = slabs[nranks // 2].get_option(sfl.capi.OPT_LAST_CHAINED)
-        got = np.concatenate([s.download(sfl.capi.FIELD_PRESSURE) for s in slabs], axis=0)
-    finally:
-        for s in slabs:
-            s.close()
-    assert chained == info["launches"] - 1 and chained >= 3, (chained, info)
-    assert info["exchanges"] >= 2, info
-    assert_bit_equal(got, want, f"{nranks} slabs, chained launches, fuse {fuse} halo {halo}")
-
-
 SMALL_SHAPES = [(2, 2), (2, 7), (7, 2), (3, 3), (4, 5), (61, 81), (80, 60), (64, 48), (127, 33), (128, 48), (78, 78),
                 (3, 2048), (2047, 3), (2, 3072), (3072, 2), (257, 23), (128, 80), (101, 101)]
 
@@ -1420,46 +1349,8 @@ def test_emulated_rank_runs_its_program_alone(sfl):
         s.synchronize()
 
 
-@pytest.mark.parametrize("mode,rank", [(1, 3), (-1, 3), (-1, 0), (64, 7)])
-def test_emulated_rank_with_chained_launches(sfl, mode, rank):
-    """The emulated rank with SFL_OPT_SOR_CHAIN: forced, automatic (a thin slab with a transport of its own chains its launches:
-    8192 columns x 1024 rows, the share of BASELINE configuration 4) and with several tiles per wave.  The rows out of the cuts'
-    reach equal the whole-domain solve bit for bit, the chains really ran, whole steps run through."""
-    dim_x, dim_y, nranks, iters = 8192, 8192, 8, 30
-    import bench
-    rows = slice(rank * 1024, (rank + 1) * 1024)
-    rng = np.random.default_rng(5 + rank)
-    d = np.zeros((dim_y, dim_x), np.float32)
-    lo, hi = max(rows.start - 192, 0), min(rows.stop + 192, dim_y)
-    d[lo:hi] = (rng.standard_normal((hi - lo, dim_x)) * 0.1).astype(np.float32)
-    # the whole-domain solve of a right-hand side that is zero away from this slab: only rows within 2 * iters of the slab matter
-    with sfl.Solver(dim_x, dim_y) as one:
-        one.upload(sfl.capi.FIELD_DIVERGENCE, d)
-        one.poisson_solve(1.0, iters, OMEGA)
-        one.synchronize()
-        want = one.download(sfl.capi.FIELD_PRESSURE)[rows]
-    with sfl.Solver(dim_x, dim_y, 0, rank, nranks) as s:
-        s.comm_emulate()
-        s.set_option(sfl.capi.OPT_SOR_CHAIN, mode)
-        s.upload(sfl.capi.FIELD_DIVERGENCE, d[rows])
-        for _ in range(2):
-            s.poisson_solve(1.0, iters, OMEGA)
-        s.synchronize()
-        info = s.last_solve_info()
-        assert s.get_option(sfl.capi.OPT_LAST_CHAINED) == info["launches"] - 1 == 5
-        got = s.download(sfl.capi.FIELD_PRESSURE)
-        reach = 2 * iters
-        inner = slice(reach if rank > 0 else 0, 1024 - (reach if rank < nranks - 1 else 0))
-        assert_bit_equal(got[inner], want[inner], f"emulated rank {rank}, chain mode {mode}: rows out of the cuts' reach")
-        s.upload(sfl.capi.FIELD_VELOCITY, bench.synthetic_velocity(dim_x, s.row_begin, s.row_end))
-        s.upload(sfl.capi.FIELD_COLOR, bench.synthetic_color(dim_x, s.row_begin, s.row_end))
-        for _ in range(2):
-            s.step(DT, 1.0, iters, OMEGA)
-        s.synchronize()
-
-
-@pytest.mark.parametrize("overlap,halo", [(1, 0), (1, 32), (0, 0)])
-def test_zero_iterations_on_slabs(sfl, overlap, halo):
+@pytest.mark.parametrize("schedule,halo", [(2, 0), (2, 32), (1, 0), (3, 0)])
+def test_zero_iterations_on_slabs(sfl, schedule, halo):
     """poisson_solve with iters == 0 still zero-fills p (poisson.cpp:117-119) -- on slabs too.  The early-exchange plan used to
     index its empty tables at n - 1 for it (found by UBSan on the host side, tests/cpp/host_san_driver.cpp)."""
     dim_x, dim_y, nranks = 256, 900, 3
@@ -1467,8 +1358,7 @@ def test_zero_iterations_on_slabs(sfl, overlap, halo):
     slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
     try:
         sfl.Solver.link_group(slabs)
-        slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
-        slabs[0].set_option(sfl.capi.OPT_SOR_ARRIVAL, 0)
+        slabs[0].set_option(sfl.capi.OPT_EXCHANGE_SCHEDULE, schedule)
         slabs[0].set_option(sfl.capi.OPT_SOR_HALO, halo)
         for s in slabs:
             s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
@@ -1506,7 +1396,7 @@ def test_emulated_rank_with_rccl_as_transport(sfl, rank, dim_x, dim_y, iters, ar
         s.comm_emulate_rccl()
         assert s.get_option(sfl.capi.OPT_TRANSPORT) == 4
         if arrival >= 0:
-            s.set_option(sfl.capi.OPT_SOR_ARRIVAL, arrival)
+            s.set_option(sfl.capi.OPT_EXCHANGE_SCHEDULE, 3 if arrival else 2)
         assert s.get_option(sfl.capi.OPT_EXCHANGE_SCHEDULE) == (2 if arrival == 0 else 3)
         s.upload(sfl.capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
         for _ in range(3):
@@ -1600,7 +1490,7 @@ def test_a_short_dye_guess_with_the_early_rows_queued_and_overlap_off(sfl, oracl
     """sfl_step queues the early interior advection (and records "velocity and dye are final") BEFORE it examines the
     last step's report; when that report says the dye's guessed halo was short, the dye is advected again -- after the event.  The
     dye's halo of the new step must not leave behind the stale event.  Forced here: large forces in step k (the guess made
-    before them is short), none in step k + 1 (the early rows are queued), SFL_OPT_SOR_OVERLAP = 0 and the baseline kernel
+    before them is short), none in step k + 1 (the early rows are queued), exchanges in line (SFL_OPT_EXCHANGE_SCHEDULE = 1) and the baseline kernel
     (no exchange of the solve on the exchange stream orders anything by accident).  Every field of every step against the
     oracle on the whole domain."""
     dim_x, dim_y, nranks, iters = 640, 1536, 2, 6
@@ -1609,7 +1499,7 @@ def test_a_short_dye_guess_with_the_early_rows_queued_and_overlap_off(sfl, oracl
         slabs = [sfl.Solver(dim_x, dim_y, 0, r, nranks) for r in range(nranks)]
         try:
             sfl.Solver.link_group(slabs)
-            slabs[0].set_option(sfl.capi.OPT_SOR_OVERLAP, overlap)
+            slabs[0].set_option(sfl.capi.OPT_EXCHANGE_SCHEDULE, 0 if overlap else 1)
             if kernel:
                 slabs[0].set_option(sfl.capi.OPT_SOR_KERNEL, kernel)
             for s in slabs:

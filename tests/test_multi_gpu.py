@@ -2,6 +2,7 @@
 RCCL halo exchanges and compares the result of the timed solve bit for bit with the reference CPU loop run on the whole domain
 (bench.py's `parity` block); the full sim step runs as well.
   * test_rccl_slab_solve_matches_reference: one rank per GPU -- needs as many GPUs as ranks (skipped on the 1-GPU test boxes);
+    nine cases in the default selection, the forced-schedule duplicates behind SFL_SLOW_MULTI_GPU=1;
   * test_rccl_ranks_as_processes_on_one_device: the same N processes and the same N-rank communicator on ONE GPU, over RCCL's
     socket transport (bench.py --share-device): runs wherever there is a GPU.
 (The in-process virtual-rank tests of test_gpu_parity.py cover the slab program itself without RCCL.)"""
@@ -31,17 +32,18 @@ def _devices():
 
 # (8, 8192, 80) is BASELINE config 4, (2 / 4, 8192, 80) its other scaling points, (8, 16384, 200) config 5 -- exactly as
 # bench.py runs them; the smaller grids exercise classic (halo < 2 x fuse) and early exchanges, with and without overlap.
-# mode: "" = the launcher's own chain of schedules (exchanges in time first; fresh ranks with early exchanges behind events, then
-# in line, should an attempt fail: the line says which schedule produced it); the others force ONE schedule, no fallback:
-# "in-time" (counted on the device), "by-event" (the library's own default on RCCL ranks), "in-line", and in-time with chained
-# launches where the slabs are thin ("chain-auto") / wherever they can run ("chain")
-MODES = {"": [], "in-time": ["--arrival-in-time"], "by-event": ["--arrival-by-event"], "in-line": ["--no-overlap"],
-         "chain-auto": ["--arrival-in-time", "--chain", "-1"], "chain": ["--arrival-in-time", "--chain", "1"]}
+# mode: "" = the launcher as the driver runs it: the HEADLINE from the library's own schedule (on RCCL ranks: one launch early, behind
+# events), fresh ranks with every exchange in line should that fail, and -- where `experiment` is set -- the in-time schedule timed
+# afterwards as `in_time_experiment`, its pressure compared with the headline's by checksum; the others force ONE schedule, no
+# fallback: "in-time" (counted on the device), "by-event", "in-line".
+MODES = {"": [], "in-time": ["--arrival-in-time"], "by-event": ["--arrival-by-event"], "in-line": ["--no-overlap"]}
 
 
-def _run_bench(nranks, size, iters, halo, mode, steps, extra=(), env_extra=None):
+def _run_bench(nranks, size, iters, halo, mode, steps, extra=(), env_extra=None, experiment=False):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--size", str(size),
            "--iters", str(iters), "--steps", str(steps), "--warmup", "1", "--sim-steps", "1", "--no-priming"] + MODES[mode] + list(extra)
+    if not experiment:
+        cmd += ["--no-experiment"]
     if halo:
         cmd += ["--sor-halo", str(halo)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SFL_BENCH_WORKER")}
@@ -56,24 +58,51 @@ def _run_bench(nranks, size, iters, halo, mode, steps, extra=(), env_extra=None)
     # the sim step's fields: every rank's rows against the same steps on one whole-domain context
     assert out.get("sim_step_parity", {}).get("bit_exact") is True, out.get("sim_step_parity")
     # which schedule produced the line; a forced schedule is the one that ran
-    assert out["exchange_mode"] in ("in-time", "by-event", "in-line")
+    assert out["exchange_mode"] in ("library default", "in-time", "by-event", "in-line")
+    assert out["numerics"]["sor_fold"] == 0 and len(out["pressure_checksums"]) == nranks
     if mode in ("in-time", "by-event", "in-line"):
-        assert out["exchange_mode"] == mode and out["fallback_from"] == []
+        assert out["exchange_mode"] == mode and out["fallback_from"] == [] and "in_time_experiment" not in out
     if mode == "":
-        print("launcher chain:", out["exchange_mode"], out["fallback_from"])
+        print("launcher:", out["exchange_mode"], out["config"]["exchange_schedule"], out["fallback_from"], out.get("in_time_experiment"))
+        # the library's own choice between separate processes: behind events (transport.cpp Rccl::arrival_by_default)
+        if out["exchange_mode"] == "library default":
+            assert out["config"]["exchange_schedule"] == "one launch early, behind events"
+    if experiment:     # BOTH in the one line -- the default as `value`, the in-time schedule as a labelled experiment
+        exp = out["in_time_experiment"]
+        assert "failed" not in exp, exp
+        assert exp["exchange_schedule"] == "in time, counted on the device" and exp["value"] > 0
+        assert exp["pressure_matches_headline_bit_for_bit"] is True
     return out, r.stderr
 
 
-@pytest.mark.parametrize("nranks,size,iters,halo,mode", [
-    (2, 2048, 40, 0, ""), (2, 2048, 40, 0, "in-time"), (2, 2048, 40, 0, "by-event"), (2, 1024, 24, 16, "in-time"), (2, 1024, 24, 12, "in-line"),
-    (4, 2048, 40, 0, ""), (8, 4096, 30, 0, "in-time"), (2, 8192, 80, 0, ""), (4, 8192, 80, 0, ""), (8, 8192, 80, 0, ""),
-    (8, 8192, 80, 0, "in-time"), (8, 8192, 80, 0, "by-event"), (8, 8192, 80, 0, "in-line"), (8, 8192, 80, 160, "in-time"),
-    (8, 8192, 80, 0, "chain-auto"), (2, 2048, 40, 0, "chain"), (4, 8192, 80, 0, "chain"), (8, 16384, 200, 0, ""),
-    (8, 16384, 200, 160, "in-time")])
-def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, mode):
+# One rank per GPU.  The default selection is budgeted for the driver's 1200 s GPU-suite limit on a node with 8 GPUs (VERDICT r05
+# item 7: at most 10 cases, tests/test_bench_launcher.py counts them): BASELINE configuration 4 at 2 / 4 / 8 GPUs as the driver
+# runs it, its in-time schedule forced, configuration 5 once, and the small grids that exercise shallow halos.  The forced-schedule
+# duplicates and the second configuration-5 case run with SFL_SLOW_MULTI_GPU=1 (tools/first_multi_gpu.sh sets it).
+REAL_GPU_CASES = [
+    (2, 2048, 40, 0, "", True), (2, 1024, 24, 16, "in-time", False), (2, 1024, 24, 12, "in-line", False), (4, 2048, 40, 0, "", False),
+    (2, 8192, 80, 0, "", False), (4, 8192, 80, 0, "", False), (8, 8192, 80, 0, "", True), (8, 8192, 80, 0, "in-time", False),
+    (8, 16384, 200, 0, "", False)]
+REAL_GPU_CASES_SLOW = [
+    (2, 2048, 40, 0, "in-time", False), (2, 2048, 40, 0, "by-event", False), (8, 4096, 30, 0, "in-time", False),
+    (8, 8192, 80, 0, "by-event", False), (8, 8192, 80, 0, "in-line", False), (8, 8192, 80, 160, "in-time", False),
+    (8, 16384, 200, 160, "in-time", False)]
+
+
+@pytest.mark.parametrize("nranks,size,iters,halo,mode,experiment", REAL_GPU_CASES)
+def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, mode, experiment):
     if _devices() < nranks:
         pytest.skip(f"needs {nranks} GPUs, {_devices()} visible")
-    _run_bench(nranks, size, iters, halo, mode, steps=14)
+    _run_bench(nranks, size, iters, halo, mode, steps=14, experiment=experiment)
+
+
+@pytest.mark.parametrize("nranks,size,iters,halo,mode,experiment", REAL_GPU_CASES_SLOW)
+def test_rccl_slab_solve_matches_reference_every_schedule(nranks, size, iters, halo, mode, experiment):
+    if not os.environ.get("SFL_SLOW_MULTI_GPU"):
+        pytest.skip("the forced-schedule duplicates run with SFL_SLOW_MULTI_GPU=1 (tools/first_multi_gpu.sh)")
+    if _devices() < nranks:
+        pytest.skip(f"needs {nranks} GPUs, {_devices()} visible")
+    _run_bench(nranks, size, iters, halo, mode, steps=14, experiment=experiment)
 
 
 # The SAME path -- N rank processes, a real N-rank RCCL communicator, matched ncclSend / ncclRecv between processes, the collective
@@ -84,17 +113,17 @@ def test_rccl_slab_solve_matches_reference(nranks, size, iters, halo, mode):
 # context), with RCCL's own log as the witness of the communicator's size.  What it cannot show: xGMI, or any timing.
 # (8, 8192, 80) is BASELINE configuration 4 exactly as the driver's 8-GPU run would execute it, but for the wire (17 s; its other
 # schedules, a 160-row halo and configuration 5 were run by hand: profiles/r05_rccl_ranks_on_one_device.txt).
-@pytest.mark.parametrize("nranks,size,iters,halo,mode", [
-    (2, 2048, 40, 0, ""), (2, 2048, 40, 0, "in-time"), (2, 2048, 40, 0, "by-event"), (2, 1024, 24, 12, "in-line"), (2, 1024, 24, 16, "in-time"),
-    (2, 2048, 40, 0, "chain"), (4, 2048, 40, 0, ""), (8, 4096, 30, 0, "by-event"), (8, 8192, 80, 0, "")])
-def test_rccl_ranks_as_processes_on_one_device(nranks, size, iters, halo, mode):
+@pytest.mark.parametrize("nranks,size,iters,halo,mode,experiment", [
+    (2, 2048, 40, 0, "", True), (2, 2048, 40, 0, "in-time", False), (2, 2048, 40, 0, "by-event", False), (2, 1024, 24, 12, "in-line", False),
+    (2, 1024, 24, 16, "in-time", False), (4, 2048, 40, 0, "", False), (8, 4096, 30, 0, "by-event", False), (8, 8192, 80, 0, "", False)])
+def test_rccl_ranks_as_processes_on_one_device(nranks, size, iters, halo, mode, experiment):
     if _devices() < 1:
         pytest.skip("needs a GPU")
     _needs_loopback()
     extra = ["--share-device", "0"]
     if "--arrival-in-time" in MODES[mode]:
         extra += ["--halo-timeout-ms", "15000"]   # (a lost message is to end as an error, not as a kernel that spins for minutes)
-    out, log = _run_bench(nranks, size, iters, halo, mode, steps=6, extra=extra,
+    out, log = _run_bench(nranks, size, iters, halo, mode, steps=6, extra=extra, experiment=experiment,
                           env_extra={"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,NET"})
     assert out["config"]["physical_gpus"] == 1 and out["config"]["ranks_share_device"] == 0
     assert "ON DEVICE 0" in out["config"]["parallelism"]
@@ -103,14 +132,18 @@ def test_rccl_ranks_as_processes_on_one_device(nranks, size, iters, halo, mode):
     assert "NET/Socket" in log, log[-3000:]
 
 
-def test_a_real_time_out_makes_the_launcher_fall_back_with_fresh_rccl_ranks():
-    """End to end, nothing simulated: four rank processes on one device, exchanges in time with a limit (1 ms) no message between
-    time-sliced processes can meet -- a wait inside a solve gives up on a real RCCL rank, that rank fails loudly, the launcher stops
-    the others and starts FRESH ranks behind events, whose result is the reference's."""
+def test_a_real_time_out_is_an_error_line_of_the_experiment_and_the_headline_stands():
+    """End to end, nothing simulated: four rank processes on one device; the in-time experiment runs with a limit (1 ms) no message
+    between time-sliced processes can meet -- a wait inside a solve gives up on a real RCCL rank, that rank fails loudly, the launcher
+    stops the others -- and the headline, measured before it by fresh ranks on the library's own schedule, is what the line reports."""
     if _devices() < 1:
         pytest.skip("needs a GPU")
     _needs_loopback()
-    out, log = _run_bench(4, 2048, 40, 0, "", steps=6, extra=["--share-device", "0", "--halo-timeout-ms", "1"])
-    assert out["exchange_mode"] == "by-event", (out["exchange_mode"], out["fallback_from"])
-    assert [f["mode"] for f in out["fallback_from"]] == ["in-time"]
-    assert "a wait inside a solve lasted longer than" in out["fallback_from"][0]["why"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--size", "2048", "--iters", "40", "--steps", "6", "--warmup", "1",
+           "--sim-steps", "1", "--no-priming", "--share-device", "0", "--halo-timeout-ms", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SFL_BENCH_WORKER")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["exchange_mode"] == "library default" and out["fallback_from"] == [] and out["parity"]["bit_exact"]
+    assert "a wait inside a solve lasted longer than" in out["in_time_experiment"]["failed"], out["in_time_experiment"]

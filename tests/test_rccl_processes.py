@@ -49,7 +49,7 @@ def run_ranks(world, scenario, seed, seconds=None, timeout=600):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_random_slab_groups_over_real_rccl_ranks(world):
-    """Seeded random shapes / iterations / fuse and halo depths / schedules (behind events, in time, in time in chained launches,
+    """Seeded random shapes / iterations / fuse and halo depths / schedules (behind events, in time,
     in line) / dx / omega / dt / velocity scales: a solve and 2-3 sim steps per configuration, all four fields of every rank."""
     results = run_ranks(world, "soak", 100 + world, seconds=10)   # (minutes of it: tools/recipes/soak.sh, leg "ranks")
     assert results[0]["cases"] >= 3, results

@@ -162,7 +162,7 @@ def test_slab_program_with_a_tail_over_gloo(tmp_path, oracle, world, fuse, iters
 @pytest.mark.parametrize("world,fuse,iters,halo,tail", [(2, 10, 40, 64, 0), (2, 10, 40, 64, 1), (3, 6, 20, 30, 3), (2, 8, 12, 16, 1),
                                                        (3, 4, 7, 4, 0), (2, 16, 24, 64, 1)])
 def test_in_time_slab_program_over_gloo(tmp_path, oracle, world, fuse, iters, halo, tail):
-    """sfl_plan_poisson kernel 3 (what SFL_OPT_SOR_ARRIVAL runs): the fused launches with in-time exchanges at EVERY halo depth --
+    """sfl_plan_poisson kernel 3 (what SFL_OPT_EXCHANGE_SCHEDULE = 3 runs): the fused launches with in-time exchanges at EVERY halo depth --
     the exchange of a superstep follows the launch that produces its rows, never precedes it -- with and without a tail
     (every superstep then holds halo - tail passes, the exchange skips the tail rows that are still exact).  Executed by
     gloo ranks with NaN ghosts: owned rows and tail rows must hold the reference's values."""

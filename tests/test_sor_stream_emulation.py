@@ -31,8 +31,6 @@ def emu():
 
     lib.emu_tiling_cover.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.emu_tiling_cover.restype = C.c_int
-    lib.emu_tiling_deps.argtypes = [C.c_int] * 13
-    lib.emu_tiling_deps.restype = C.c_int
     lib.emu_tile_order.argtypes = [C.c_int] * 13
     lib.emu_tile_order.restype = C.c_int
 
@@ -142,32 +140,6 @@ def test_tilings_partition_the_row_range(emu):
                 assert cover[:g_begin].sum() == 0 and cover[g_end:].sum() == 0, tag
                 counts[balance] = n
             assert counts[10] >= counts[0]
-
-
-def test_dependencies_between_two_tilings(emu):
-    """Chained supersteps (sor_chain_kernel): a tile waits for the tiles of the PREVIOUS superstep's tiling -- other rows per
-    tile, another row range -- whose output it reads or whose input it overwrites.  The product finds them by arithmetic
-    (chunks_touching / tile_index); here against a brute-force search, on thin-slab shapes and random ones."""
-    rng = np.random.default_rng(23)
-    cases = [(10, 8192, 8192, 960, 2112, 41, 970, 2102, 41, 13), (10, 8192, 8192, 1024, 2048, 41, 960, 2112, 36, 13),
-             (16, 8192, 8192, 0, 8192, 234, 0, 8192, 234, 19), (8, 300, 200, 0, 200, 30, 0, 200, 17, 12)]
-    for _ in range(200):
-        ns = int(rng.choice([2, 4, 8, 10, 12, 16]))
-        dim_x, gdim_y = int(rng.integers(2, 900)), int(rng.integers(2, 500))
-        def rows():
-            b = int(rng.integers(0, gdim_y))
-            e = int(rng.integers(b + 1, gdim_y + 1))
-            if rng.random() < 0.3:
-                b, e = 0, gdim_y
-            return b, e, int(rng.integers(1, e - b + 1))
-        cases.append((ns, dim_x, gdim_y) + rows() + rows() + (ns + int(rng.integers(0, 6)),))
-    total = 0
-    for ns, dim_x, gdim_y, a0, a1, arpc, b0, b1, brpc, reach in cases:
-        for balance in (0, 10):
-            n = emu.lib.emu_tiling_deps(ns, 128, 2, dim_x, gdim_y, a0, a1, arpc, b0, b1, brpc, balance, reach)
-            assert n >= 0, (ns, dim_x, gdim_y, a0, a1, arpc, b0, b1, brpc, reach, balance)
-            total += n
-    assert total > 1000
 
 
 def test_dispatch_order_is_a_bijection_with_the_free_tiles_first(emu):

@@ -26,10 +26,9 @@ for rep in $(seq $REPS); do
     python - gpurun_out/emulate_$TAG.json $rep <<'PY' | tee -a $OUT
 import json, sys
 d = json.load(open(sys.argv[1]))
-print("rep %s rank %d of %d  %-12s wire %3d us  %.4f ms per solve (events %.4f)  %7.1f us per sim step  %d launches %d exchanges  %s%s" % (
+print("rep %s rank %d of %d  %-12s wire %3d us  %.4f ms per solve (events %.4f)  %7.1f us per sim step  %d launches %d exchanges  %s" % (
     sys.argv[2], d["emulated_rank"], d["of"], d["transport"], d["emulated_wire_us"], d["ms_per_solve"], d["ms_per_solve_hip_events"],
-    d["sim_step_us"] or float("nan"), d["sor_launches_per_solve"], d["halo_exchanges_per_solve"], d["exchange_schedule"],
-    "  chained %d" % d["supersteps_in_chained_launches"] if d["supersteps_in_chained_launches"] else ""))
+    d["sim_step_us"] or float("nan"), d["sor_launches_per_solve"], d["halo_exchanges_per_solve"], d["exchange_schedule"]))
 PY
   done; done; done
 done

@@ -2,7 +2,8 @@
 # N RCCL ranks as N processes on ONE GPU (bench.py --share-device 0: every rank its own NCCL_HOSTID, RCCL's socket transport over
 # loopback between them), every exchange schedule, parity of every rank's rows.  ON THE GPU BOX:
 #   gpurun -- bash tools/recipes/shared_device_ranks.sh <tag> "<N size iters halo mode>" ["<N size iters halo mode>" ...]
-#   mode: chain | in-time | by-event | in-line | chained   (chain = the launcher's own chain of schedules)
+#   mode: chain | in-time | by-event | in-line   (chain = the launcher as the driver runs it: library default, in line as the fallback,
+#         the in-time experiment behind the headline)
 # Result lines: gpurun_out/shared_<tag>.txt ; the last run's RCCL log (NCCL_DEBUG=INFO) in gpurun_out/shared_<tag>_rccl.log
 set -u
 export TMPDIR=/tmp
@@ -10,8 +11,7 @@ TAG=$1; shift
 OUT=gpurun_out/shared_$TAG.txt; mkdir -p gpurun_out; : > $OUT
 for spec in "$@"; do
   set -- $spec; n=$1 size=$2 iters=$3 halo=$4 mode=$5
-  case $mode in chain) m="";; in-time) m="--arrival-in-time --halo-timeout-ms 15000";; by-event) m="--arrival-by-event";; in-line) m="--no-overlap";;
-                chained) m="--arrival-in-time --chain 1 --halo-timeout-ms 15000";; esac
+  case $mode in chain) m="";; in-time) m="--arrival-in-time --halo-timeout-ms 15000";; by-event) m="--arrival-by-event";; in-line) m="--no-overlap";; esac
   h=""; [ "$halo" != 0 ] && h="--sor-halo $halo"
   t0=$(date +%s.%N)
   NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,NET timeout 900 python bench.py --gpus $n --share-device 0 --size $size --iters $iters --steps 6 --warmup 1 --sim-steps 1 --no-priming $m $h \

@@ -5,14 +5,13 @@
 #                         rccl      tools/soak_transport.py ... rccl: one rank's program with RCCL-to-self as the transport
 #                         copy      tools/soak_transport.py ... copy: ... with self-copies
 #                         unaligned tools/unaligned_stress.py: pitches that are not whole cache lines, both arrival modes
-#                         chain     tools/chain_stress.py: chained launches, whole domains and 2 / 3 virtual ranks
 #                         ranks     tests/rccl_rank_worker.py --spawn N soak: 2 / 3 / 4 RANK PROCESSES, one real RCCL communicator on
 #                                   device 0 (NCCL_HOSTID per rank, socket transport), random slab groups against the oracle
 # Result lines: gpurun_out/soak_<tag>.txt (every leg ends with its count of mismatches; the script's status is non-zero on any)
 set -u
 export TMPDIR=/tmp
 TAG=$1 SECS=$2; shift 2
-LEGS=${*:-"fuzz overlap rccl copy unaligned chain ranks"}
+LEGS=${*:-"fuzz overlap rccl copy unaligned ranks"}
 OUT=gpurun_out/soak_$TAG.txt; mkdir -p gpurun_out; : > $OUT
 rc=0
 run() { echo "## $*" >> $OUT; "$@" 2>/dev/null | grep -v "^$" | tail -6 >> $OUT || rc=1; }
@@ -22,7 +21,6 @@ for leg in $LEGS; do case $leg in
   rccl)      run python tools/soak_transport.py 63 $SECS rccl;;
   copy)      run python tools/soak_transport.py 64 $SECS copy;;
   unaligned) run python tools/unaligned_stress.py $SECS 1; run python tools/unaligned_stress.py $((SECS / 2)) 0;;
-  chain)     GPU_MAX_HW_QUEUES=8 run python tools/chain_stress.py $SECS 17;;
   ranks)     for w in 2 3 4; do run python tests/rccl_rank_worker.py --spawn $w soak $((70 + w)) $((SECS / 2)); done
              run python tests/rccl_rank_worker.py --spawn 3 soak 79 $((SECS / 2)) big;;
 esac; done

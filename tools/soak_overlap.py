@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
         slabs[0].set_option(capi.OPT_SOR_KERNEL, 2)
         slabs[0].set_option(capi.OPT_SOR_FUSE, fuse)
         slabs[0].set_option(capi.OPT_SOR_HALO, halo)
-        slabs[0].set_option(capi.OPT_SOR_ARRIVAL, int(rng.integers(0, 4) > 0))   # mostly the device-side arrival count
+        slabs[0].set_option(capi.OPT_EXCHANGE_SCHEDULE, 3 if int(rng.integers(0, 4)) > 0 else 2)   # mostly the device-side arrival count
         for rep in range(3):          # back-to-back solves on the same contexts: stale ghost rows, swapped buffers
             for s in slabs:
                 s.upload(capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])

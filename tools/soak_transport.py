@@ -60,8 +60,7 @@ while time.time() - t0 < budget or solves < min_solves:
             s.comm_emulate()
         s.set_option(capi.OPT_SOR_FUSE, fuse)
         s.set_option(capi.OPT_SOR_HALO, halo)
-        s.set_option(capi.OPT_SOR_ARRIVAL, arrival)
-        s.set_option(capi.OPT_SOR_OVERLAP, overlap)
+        s.set_option(capi.OPT_EXCHANGE_SCHEDULE, 1 if not overlap else (3 if arrival else 2))
         sched = s.get_option(capi.OPT_EXCHANGE_SCHEDULE)
         s.upload(capi.FIELD_DIVERGENCE, d[b:e])
         configs += 1

@@ -1,6 +1,6 @@
 """r04: stress of the overlapped slab executor on row pitches that are NOT a multiple of the 128-byte cache line (a line then holds
 the end of a ghost row and the beginning of an owned row), short slabs, shallow fuse depths: many exchanges per solve.
-usage: unaligned_stress.py <seconds> <SFL_OPT_SOR_ARRIVAL 0|1>"""
+usage: unaligned_stress.py <seconds> <0 = exchanges behind events | 1 = in time>"""
 import sys, time, importlib
 import numpy as np
 sys.path.insert(0, ".")
@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
         slabs[0].set_option(capi.OPT_SOR_KERNEL, 2)
         slabs[0].set_option(capi.OPT_SOR_FUSE, fuse)
         slabs[0].set_option(capi.OPT_SOR_HALO, halo)
-        slabs[0].set_option(capi.OPT_SOR_ARRIVAL, arrival)
+        slabs[0].set_option(capi.OPT_EXCHANGE_SCHEDULE, 3 if arrival else 2)
         for s in slabs:
             s.upload(capi.FIELD_DIVERGENCE, d[s.row_begin:s.row_end])
         for rep in range(8):
@@ -48,4 +48,4 @@ while time.time() - t0 < budget:
     finally:
         for s in slabs:
             s.close()
-print(f"SFL_OPT_SOR_ARRIVAL {arrival}: {cases} solves on unaligned pitches in {time.time() - t0:.0f} s: {bad} mismatches", flush=True)
+print(f"exchanges {'in time' if arrival else 'behind events'}: {cases} solves on unaligned pitches in {time.time() - t0:.0f} s: {bad} mismatches", flush=True)

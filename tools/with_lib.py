@@ -23,6 +23,7 @@ if __name__ == "__main__":
     capi = importlib.import_module("esp32-fluid-simulation_amd._capi")
     assert capi._lib is None, "with_lib.py: the product library is already loaded (something loaded it at import time)"
     capi.LIB_PATH = lib
+    os.environ["SFL_WITH_LIB"] = lib     # bench.py's launchers start their rank processes through this script too (worker_argv)
     loaded = capi.lib()
     assert os.path.samefile(loaded._name, lib), f"with_lib.py: loaded {loaded._name}, asked for {lib}"
     sys.argv = [script] + sys.argv[3:]
