@@ -351,7 +351,7 @@ def parse_args(argv=None):
 # failure costs the line nothing.
 PLAN = [("library default", [], "headline"),
         ("in-line", ["--no-overlap"], "fallback"),
-        ("in-time", ["--arrival-in-time", "--no-cpu-baseline", "--sim-steps", "0", "--halo-timeout-ms", "20000"], "experiment")]
+        ("in-time", ["--arrival-in-time", "--no-cpu-baseline", "--sim-steps", "0"], "experiment")]
 TOTAL_BUDGET_S = 1500.0
 EXPERIMENT_BUDGET_S = 150.0
 
@@ -362,7 +362,10 @@ def attempt_plan(args):
     forced = "in-time" if args.arrival_in_time else "by-event" if args.arrival_by_event else "in-line" if args.no_overlap else None
     if forced:
         return [(forced, [], "headline")]
-    return [p for p in PLAN if not (p[2] == "experiment" and args.no_experiment)]
+    plan = [p for p in PLAN if not (p[2] == "experiment" and args.no_experiment)]
+    if not args.halo_timeout_ms:   # a lost message of the experiment is to end as an error line, not as a stopped process
+        plan = [(m, f + ["--halo-timeout-ms", "20000"] if r == "experiment" else f, r) for m, f, r in plan]
+    return plan
 
 
 def mode_of(args):

@@ -8,17 +8,19 @@ def short(name):
     import re
     # sor_fused_kernel<Lane2<NS, VEC, ZERO_IN[, NT]> | Lane4<NS, ZERO_IN>, NS, DX1, ZERO_IN>
     # (the store policy ST is an int since round 4 -- 0 plain, 2 nt, 16 sc1 -- and was a bool NT before)
-    # (... and a load policy LD since the chained launch: Lane2<NS, VEC, ZERO_IN, ST, LD>.  Every template argument that tells two
-    # instantiations apart is kept: NS, dx1, zero_in and the cache policies -- VERDICT r04: a truncated name had merged the
-    # zero_in = true and zero_in = false kernels into one row)
-    m = re.search(r"(sor_fused_kernel|sor_chain_kernel)<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)((?:, \d+)*)>, \d+, (true|false)(?:, (true|false))?>", name)
+    # (rounds 4 - 5 also carried a load policy LD for the chained launch, Lane2<NS, VEC, ZERO_IN, ST, LD>; round 6 retired it and added
+    # the arithmetic: Lane2<NS, VEC, ZERO_IN, ST, FOLD>.  Every template argument that tells two instantiations apart is kept: NS,
+    # dx1, zero_in, the store policy and the arithmetic -- VERDICT r04: a truncated name had merged the zero_in = true and
+    # zero_in = false kernels into one row)
+    m = re.search(r"(sor_fused_kernel|sor_chain_kernel)<.*?Lane(\d)<(\d+)((?:, (?:true|false))+)((?:, \d+)*)((?:, (?:true|false))*)>, \d+, (true|false)(?:, (true|false))?>", name)
     if m:
         flags = [f == "true" for f in re.findall(r"true|false", m.group(4))]
         pol = re.findall(r"\d+", m.group(5))
         st = {"2": "nt", "16": "sc1"}.get(pol[0] if pol else "", "nt" if (m.group(2) == "2" and len(flags) >= 3 and flags[2]) else "")
         ld = {"16": "+ldsc1"}.get(pol[1] if len(pol) > 1 else "", "")
-        zero = f", zero_in={m.group(7)}" if m.group(7) else ""
-        return f"{m.group(1)}<Lane{m.group(2)}{st}{ld}, NS={m.group(3)}, dx1={m.group(6)}{zero}>"
+        fold = ", fold" if "true" in m.group(6) else ""      # (SFL_OPT_SOR_FOLD = 1; nothing: the reference's two products)
+        zero = f", zero_in={m.group(8)}" if m.group(8) else ""
+        return f"{m.group(1)}<Lane{m.group(2)}{st}{ld}, NS={m.group(3)}, dx1={m.group(7)}{zero}{fold}>"
     m = re.search(r"(advect_divergence_tiled_kernel|advect_vec2f_tiled_kernel|advect_vec3uq32_tiled_kernel)<([^>]*)>", name)
     if m:
         flags = re.findall(r"true|false", m.group(2))

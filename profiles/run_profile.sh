@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --sim-steps 0 $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --sim-steps 0 --no-fold-leg $*"
 # 1. kernel trace + stats (no counters in this pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 # 2. counters, one block of counters per pass (kernel-trace only, as the guide prescribes)

@@ -7,7 +7,7 @@ set -u
 OUT=$PWD/gpurun_out/prof_step_${1:-pmc}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --sim-steps ${SIM_STEPS:-8}"   # sfl_step_n(n): n - 1 launches of the seam kernel per pass
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-fold-leg --sim-steps ${SIM_STEPS:-8}"   # sfl_step_n(n): n - 1 launches of the seam kernel per pass
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o trace -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_')

@@ -28,7 +28,35 @@ def test_host_side_under_asan_and_ubsan():
 
 
 def test_launch_stubs_match_the_launch_interface():
-    """tests/cpp/launch_stubs.cpp is generated from csrc/kernels.h: regenerating it must change nothing."""
-    before = open(os.path.join(CPP, "launch_stubs.cpp")).read()
+    """tests/cpp/launch_stubs.cpp and launch_stubs_ok.cpp are generated from csrc/kernels.h: regenerating them must change nothing."""
+    before = [open(os.path.join(CPP, f)).read() for f in ("launch_stubs.cpp", "launch_stubs_ok.cpp")]
     subprocess.run(["python3", os.path.join(CPP, "make_launch_stubs.py")], check=True, stdout=subprocess.DEVNULL)
-    assert open(os.path.join(CPP, "launch_stubs.cpp")).read() == before
+    assert [open(os.path.join(CPP, f)).read() for f in ("launch_stubs.cpp", "launch_stubs_ok.cpp")] == before
+
+
+def test_host_side_from_four_threads_under_tsan():
+    """`make -C tests/cpp tsan_host` -- the host units over a HIP / RCCL runtime that lives on the host
+    (tests/cpp/fake_hip.cpp) and kernels that do nothing (launch_stubs_ok.cpp), RUN from four threads at once under ThreadSanitizer:
+    per thread a whole-domain context (options, I/O, steps, force queue), a linked group of 2 - 4 virtual ranks through every
+    exchange schedule, one rank's program over the one-rank RCCL transport, and the host-pointer drop-ins with their per-thread
+    context cache; all threads share the error state and the plan queries.  Clean -- and the harness is shown to see a race
+    when there is one (two threads, one plain int)."""
+    subprocess.run(["make", "-C", CPP, "tsan_host"], check=True, stdout=subprocess.DEVNULL)
+    exe = os.path.join(CPP, "host_tsan_driver")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66:second_deadlock_stack=1")
+    r = subprocess.run([exe, "4", "6"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "0 failed checks, 0 allocations left" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    r = subprocess.run([exe, "race"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 66 and "ThreadSanitizer: data race" in r.stderr
+
+
+def test_host_side_runs_through_under_asan_over_the_fake_runtime():
+    """The same driver under AddressSanitizer + UBSan: here the executors, groups and transports really execute (the launch stubs
+    of test_host_side_under_asan_and_ubsan stop every operator at its first launch), and every fake-device allocation must be freed."""
+    subprocess.run(["make", "-C", CPP, "asan_fake_host"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(CPP, "host_asan_fake_driver"), "2", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "0 failed checks, 0 allocations left" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
