@@ -71,6 +71,13 @@ __device__ __forceinline__ float2 sample_global_projected(const float2 *v, const
 #ifndef SEAM_DYE_LOADS
 #define SEAM_DYE_LOADS 0   // where the dye window's loads are issued: 0 = behind the velocity's advection, 1 = in front of it (A/B)
 #endif
+#ifndef SEAM_MOCK_NO_P
+#define SEAM_MOCK_NO_P 0   // TIMING MOCK (wrong results): the pressure window is not loaded -- what would the seam cost if the last launch of
+                           // the solve handed the pressure over without memory? (profiles/r06_pressure_never_stored.txt)
+#endif
+#if SEAM_MOCK_NO_P && !defined(SFL_ALLOW_TIMING_MOCKS)
+#error "SEAM_MOCK_NO_P is a timing mock (wrong results): diagnostic builds only (tools/recipes/build_variant.sh lib ... with -DSFL_ALLOW_TIMING_MOCKS)"
+#endif
 constexpr int kThreadsSeam = 512;
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS, 6)
@@ -108,7 +115,8 @@ seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *
         for (int k = 0; k < kLoadsP; ++k) {
             const int e = threadIdx.x + k * THREADS;
             const int r = e / kPX, gi = px0 + (e - r * kPX), gj = py0 + r;
-            got_p[k] = (r < kPY && gi >= 0 && gi <= i_max && gj >= 0 && gj <= j_max) ? pressure[lcell(g, gi, gj)] : 0.0f;
+            got_p[k] = (!SEAM_MOCK_NO_P && r < kPY && gi >= 0 && gi <= i_max && gj >= 0 && gj <= j_max) ? pressure[lcell(g, gi, gj)]
+                                                                                                       : (SEAM_MOCK_NO_P ? (float)(gi + gj) : 0.0f);
         }
 #pragma unroll
         for (int k = 0; k < kLoadsV; ++k) {

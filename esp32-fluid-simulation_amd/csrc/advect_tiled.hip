@@ -34,15 +34,32 @@ struct TileGrid {
     int per_xcd;  // tiles per XCD (rounded up)
 };
 
-// Workgroups are dispatched round-robin over the 8 XCDs: block b runs on XCD b % 8.  Give XCD k the
-// k-th contiguous eighth of the tiles (row-major), so that neighbouring tiles share an L2.
+// Workgroups are dispatched round-robin over the 8 XCDs: block b runs on XCD b % 8.  Give XCD k the k-th contiguous eighth of the
+// tiles, so that neighbouring tiles share an L2 -- in an order in which the sharing happens while the lines are still there:
+// STRIP-major.  A tile re-reads its neighbours' margins (window of kR.. cells around 64 x 32 cells: 31 % more rows, 16 % more
+// columns); an XCD holds ~96 tiles at a time, and in plain row-major order (rounds 2 - 5) the tile ABOVE came a whole row of tiles
+// later -- 128 tiles at 8192 columns, 12 MB of traffic ago, long evicted from the 4 MB L2.  Strips of kStripTiles tile columns are
+// walked row by row instead: the tile above is kStripTiles positions away, resident at the same time or just finished (8192^2:
+// every XCD walks one strip of 16 x 256 tiles top to bottom).  Speed only: any placement computes the same result.
+#ifndef SFL_STRIP_TILES
+#define SFL_STRIP_TILES 32   // (a build-time knob for the sweep: tools/recipes/build_variant.sh)
+#endif
+constexpr int kStripTiles = SFL_STRIP_TILES;
 __device__ __forceinline__ bool tile_of_block(const TileGrid &t, int &tx, int &ty)
 {
     const int b = blockIdx.x;
-    const int tile = (b % kXcds) * t.per_xcd + b / kXcds;
-    if (tile >= t.nx * t.ny || b / kXcds >= t.per_xcd) return false;
-    ty = tile / t.nx;
-    tx = tile - ty * t.nx;
+    const int q = (b % kXcds) * t.per_xcd + b / kXcds;   // position in the strip-major order
+    if (q >= t.nx * t.ny || b / kXcds >= t.per_xcd) return false;
+    if (kStripTiles <= 0) {   // (row-major, as before)
+        ty = q / t.nx;
+        tx = q - ty * t.nx;
+        return true;
+    }
+    const int per_strip = kStripTiles * t.ny;
+    const int s = q / per_strip, r = q - s * per_strip;
+    const int w = min(kStripTiles, t.nx - s * kStripTiles);   // the last strip may be narrower
+    ty = r / w;
+    tx = s * kStripTiles + (r - ty * w);
     return true;
 }
 

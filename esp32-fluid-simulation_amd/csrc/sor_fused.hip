@@ -77,7 +77,7 @@ struct WaveTrace {
 #error "SFL_PROBE_COOP is a timing mock (wrong results): only with SFL_SOR_TRACE (tools/sor_clock_probe.hip)"
 #endif
 static_assert(SFL_PROBE_NO_LDS == 0 && SFL_PROBE_NO_LOAD == 0 && SFL_PROBE_SHIFT == 0 && SFL_PROBE_NO_EDGE == 0 &&
-                  SFL_PROBE_P_LOAD_AUX == 0 && SFL_PROBE_P_STORE_AUX == 0,
+                  SFL_PROBE_P_LOAD_AUX == 0 && SFL_PROBE_P_STORE_AUX == 0 && SFL_PROBE_NO_STORE == 0,
               "SFL_PROBE_* switches give wrong results: diagnostic builds only (define SFL_SOR_TRACE, tools/sor_clock_probe.hip)");
 #endif
 constexpr int min_waves_per_simd(int ns) { return ns == 14 ? 2 : ns >= 12 ? SFL_MIN_WAVES_DEEP : 4; }

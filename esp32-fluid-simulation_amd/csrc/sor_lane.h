@@ -30,6 +30,10 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #ifndef SFL_PROBE_P_STORE_AUX
 #define SFL_PROBE_P_STORE_AUX 0  // diagnostic builds only: ... of the p stores (16 = sc1: written through the XCD's L2)
 #endif
+#ifndef SFL_PROBE_NO_STORE
+#define SFL_PROBE_NO_STORE 0  // diagnostic builds only: the finished rows are not stored (what would a last launch
+                              // of a solve cost whose pressure nobody reads from memory? profiles/r06_pressure_never_stored.txt)
+#endif
 #ifndef SFL_PROBE_SHIFT
 #define SFL_PROBE_SHIFT 0  // diagnostic builds only (tools/sor_clock_probe.hip): 1 = no lane shift at all, 2 = row_shr / row_shl
 #endif
@@ -232,6 +236,10 @@ struct Lane2 : WaveCommon {
 
     __device__ __forceinline__ void store_row(int r, V a, V b) const
     {
+        if (SFL_PROBE_NO_STORE) {   // (the values stay "used": the relaxations are not optimised away)
+            asm volatile("" ::"v"(a), "v"(b));
+            return;
+        }
         const int soff = row_bytes(r);
         if (VEC) {
             if (a_out) {

@@ -16,13 +16,13 @@ CSRC = os.path.join(ROOT, "esp32-fluid-simulation_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.parametrize("flag", ["-DSFL_PROBE_NO_LOAD=1", "-DSFL_PROBE_SHIFT=1", "-DSFL_PROBE_COOP=3"])
+@pytest.mark.parametrize("flag", ["-DSFL_PROBE_NO_LOAD=1", "-DSFL_PROBE_SHIFT=1", "-DSFL_PROBE_COOP=3", "-DSFL_PROBE_NO_STORE=1", "-DSEAM_MOCK_NO_P=1"])
 def test_a_product_build_refuses_the_diagnostic_switches(flag):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    group = "2"
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fsyntax-only", f"-DSFL_NS_GROUP={group}",
-                        "-DSFL_DX_PART=0", flag, os.path.join(CSRC, "sor_fused.hip")], capture_output=True, text=True, timeout=600)
+    source = "advect_tiled.hip" if "SEAM" in flag else "sor_fused.hip"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fsyntax-only", "-DSFL_NS_GROUP=2",
+                        "-DSFL_DX_PART=0", "-DSFL_FOLD_PART=0", flag, os.path.join(CSRC, source)], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert "diagnostic builds only" in r.stderr or "only with SFL_SOR_TRACE" in r.stderr, r.stderr[-1500:]
 

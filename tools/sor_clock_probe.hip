@@ -14,6 +14,7 @@
 // Run:  sor_clock_probe_ns16 <dim_x> <dim_y> [launches] [rows_per_chunk] [csv path] [loop seconds]
 #define SFL_SOR_TRACE 1
 #define SFL_DX_PART 0
+#define SFL_FOLD_PART 0
 #include "../esp32-fluid-simulation_amd/csrc/sor_fused.hip"
 
 #include <algorithm>
@@ -28,7 +29,7 @@
 #endif
 #define PASTE2(a, b, c) a##b##c
 #define PASTE(a, b, c) PASTE2(a, b, c)
-#define PROBE_LAUNCH PASTE(launch_sor_fused_ns, PROBE_NS, _p0)
+#define PROBE_LAUNCH PASTE(launch_sor_fused_ns, PROBE_NS, _p0_f0)
 
 #define CK(x)                                                                             \
     do {                                                                                  \
