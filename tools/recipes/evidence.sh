@@ -8,7 +8,7 @@ R=${ROUND:-r06}   # the round the files are named after
 mkdir -p gpurun_out/$R
 bash profiles/run_profile.sh ${R}_default > /dev/null 2>&1
 bash profiles/run_profile.sh ${R}_slab1024 --size 8192 --dim-y 1024 > /dev/null 2>&1
-SIM_STEPS=20 bash profiles/run_step_pmc.sh $R > /dev/null 2>&1
+SIM_STEPS=40 bash profiles/run_step_pmc.sh $R > /dev/null 2>&1
 python bench.py > gpurun_out/$R/bench_default.json 2> gpurun_out/$R/bench_default.err
 python bench.py --size 61 --dim-y 81 --iters 20 --steps 50 --warmup 10 > gpurun_out/$R/bench_c1.json 2>/dev/null
 python bench.py --size 2048 --iters 40 --steps 30 --warmup 5 > gpurun_out/$R/bench_c2.json 2>/dev/null
