@@ -1,6 +1,8 @@
 """Test infrastructure, run by hand on a GPU box (python tests/fuzz_vs_oracle.py <seed> <seconds>): fuzz of the
 single-GPU product path against the oracle (checker only): random grid shapes, kernel options, fuse
-depths, dx / omega / dt, velocity scales; whole steps through sfl_step_n (all four fields), stand-alone solves and
+depths, dx / omega / dt, velocity scales, and -- since round 6 -- field TEXTURES: dense noise, a quiescent field with sparse forcing
+at 60..130 iterations (the solution's front decays through the denormals: where round 5's folded product left the reference's bits),
+and fields scaled down to the bottom of the float range; whole steps through sfl_step_n (all four fields), stand-alone solves and
 advect<T, float> of a random element type, bit for bit."""
 import sys, time, importlib
 import numpy as np
@@ -39,9 +41,20 @@ while time.time() - t0 < budget:
             capi.OPT_STEP_SEAMS: int(rng.choice([1, 1, 0]))}
     n_steps = int(rng.choice([2, 2, 3]))          # through sfl_step_n: the seam kernel between the steps where it applies
     channels, uq = int(rng.integers(1, 4)), bool(rng.integers(0, 2))   # advect<T, float> of another element type
+    texture = str(rng.choice(["dense", "dense", "sparse", "tiny"]))
     v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * vamp).astype(np.float32)
     c = rng.integers(0, 2 ** 31, (dim_y, dim_x, 3), dtype=np.uint32)
     d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
+    if texture == "sparse":      # zero but for a few cells (ino:199, 264-269), enough iterations for the front to reach the denormals
+        keep = rng.random((dim_y, dim_x)) < 3.0 / (dim_x * dim_y)
+        keep[rng.integers(0, dim_y), rng.integers(0, dim_x)] = True
+        d = np.where(keep, d * np.float32(rng.choice([1.0, 40.0, 1e-20])), np.float32(0.0)).astype(np.float32)
+        v = np.where(keep[..., None], v, np.float32(0.0)).astype(np.float32)
+        if not big:
+            iters = int(rng.integers(60, 130))
+    elif texture == "tiny":      # the whole field at the bottom of the float range
+        scale = np.float32(2.0 ** -int(rng.integers(100, 146)))
+        d, v = (d * scale).astype(np.float32), (v * scale).astype(np.float32)
     with sfl.Solver(dim_x, dim_y) as s:
         for k, val in opts.items():
             s.set_option(k, val)
@@ -67,6 +80,6 @@ while time.time() - t0 < budget:
     cases += 1
     if not ok:
         bad += 1
-        print(f"MISMATCH {dim_x}x{dim_y} iters {iters} dx {dx} omega {omega} dt {dt} vamp {vamp} options {opts}", flush=True)
-print(f"{cases} random configurations (solve + 2-3 steps through sfl_step_n + one generic advection each) against the oracle in {time.time() - t0:.0f} s: {bad} mismatches")
+        print(f"MISMATCH {dim_x}x{dim_y} {texture} iters {iters} dx {dx} omega {omega} dt {dt} vamp {vamp} options {opts}", flush=True)
+print(f"{cases} random configurations (dense, sparse and denormal-range fields; solve + 2-3 steps through sfl_step_n + one generic advection each) against the oracle in {time.time() - t0:.0f} s: {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -110,7 +110,18 @@ def scenario_soak():
         v = (rng.uniform(-1, 1, (dim_y, dim_x, 2)) * vamp).astype(np.float32)
         c = rng.integers(0, 2 ** 31, (dim_y, dim_x, 3), dtype=np.uint32)
         d = rng.standard_normal((dim_y, dim_x)).astype(np.float32)
-        tag = f"{world} ranks {dim_x}x{dim_y} iters {iters} dx {dx} omega {omega} dt {dt} vamp {vamp} {sched} options {opts}"
+        texture = str(rng.choice(["dense", "dense", "sparse", "tiny"]))      # (round 6: the textures of tests/fuzz_vs_oracle.py)
+        if texture == "sparse":      # a quiescent field with sparse forcing, enough iterations for the front to reach the denormals
+            keep = rng.random((dim_y, dim_x)) < 3.0 / (dim_x * dim_y)
+            keep[rng.integers(0, dim_y), rng.integers(0, dim_x)] = True
+            d = np.where(keep, d * np.float32(rng.choice([1.0, 40.0, 1e-20])), np.float32(0.0)).astype(np.float32)
+            v = np.where(keep[..., None], v, np.float32(0.0)).astype(np.float32)
+            if not big:
+                iters = int(rng.integers(60, 110))
+        elif texture == "tiny":
+            scale = np.float32(2.0 ** -int(rng.integers(100, 146)))
+            d, v = (d * scale).astype(np.float32), (v * scale).astype(np.float32)
+        tag = f"{world} ranks {dim_x}x{dim_y} {texture} iters {iters} dx {dx} omega {omega} dt {dt} vamp {vamp} {sched} options {opts}"
         ok = True
         try:
             with sfl.Solver(dim_x, dim_y, device=0, rank=rank, nranks=world) as s:
