@@ -78,7 +78,10 @@ __device__ __forceinline__ float2 sample_global_projected(const float2 *v, const
 #if SEAM_MOCK_NO_P && !defined(SFL_ALLOW_TIMING_MOCKS)
 #error "SEAM_MOCK_NO_P is a timing mock (wrong results): diagnostic builds only (tools/recipes/build_variant.sh lib ... with -DSFL_ALLOW_TIMING_MOCKS)"
 #endif
-constexpr int kThreadsSeam = 512;
+#ifndef SEAM_THREADS
+#define SEAM_THREADS 512
+#endif
+constexpr int kThreadsSeam = SEAM_THREADS;
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS, 6)
 seam_tiled_kernel(uint32_t *__restrict__ next_col, const uint32_t *col, float2 *__restrict__ next_v,

@@ -24,7 +24,10 @@ using namespace advect_math;
 
 // Measured at 8192^2 (tools/r02_runs/r02_run26.sh): tiles of 16 / 32 / 64 rows 188 / 190 / 235 us (velocity),
 // margins of 2 / 4 / 6 cells 209 / 190 / 194 us on per-cell noise of +-3.3 cells -- 32 rows, 4 cells.
-constexpr int kTX = 64, kTY = 32;        // output cells of a tile
+#ifndef SFL_TILE_ROWS
+#define SFL_TILE_ROWS 32   // (build-time knobs for sweeps: tools/recipes/build_variant.sh)
+#endif
+constexpr int kTX = 64, kTY = SFL_TILE_ROWS;        // output cells of a tile
 constexpr int kR = 4;                    // margin of the staged window (cells)
 constexpr int kSX = kTX + 2 * kR, kSY = kTY + 2 * kR;
 constexpr int kXcds = 8;
@@ -542,7 +545,10 @@ advect_vec3uq32_tiled_kernel(uint32_t *__restrict__ next_p, const uint32_t *p, f
 // threads per block: the dye kernel's window takes 34.5 KB of LDS (4 blocks per CU), so it needs 8 waves
 // per block to fill a CU (392 us at 8192^2 against 404 with 4); the velocity kernel's 23 KB leave room
 // for 6 blocks of 4 waves (193 us either way)
-constexpr int kThreadsVec2 = 256, kThreadsDye = 512;
+#ifndef SFL_DYE_THREADS
+#define SFL_DYE_THREADS 512
+#endif
+constexpr int kThreadsVec2 = 256, kThreadsDye = SFL_DYE_THREADS;
 
 TileGrid tile_grid(int dim_x, int rows)
 {
