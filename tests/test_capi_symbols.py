@@ -23,6 +23,17 @@ def test_library_exports_every_declared_symbol(sfl):
     assert sorted(sfl.capi.SIGNATURES) == declared, "ctypes table out of sync with include/sfl.h"
 
 
+def test_option_numbers_of_the_binding_match_the_header(sfl):
+    """Every SFL_OPT_* of include/sfl.h has the same number in the ctypes binding and vice versa -- round 6 retired four
+    options (8, 13, 15, 16) and added one: nobody may go on using a retired number under an old name."""
+    text = open(os.path.join(ROOT, "include", "sfl.h")).read()
+    header = {name: int(num) for name, num in re.findall(r"#define SFL_(OPT_\w+)\s+(\d+)", text)}
+    binding = {k: v for k, v in vars(sfl.capi).items() if k.startswith("OPT_") and isinstance(v, int)}
+    assert header == binding
+    assert len(set(header.values())) == len(header) and not {8, 13, 15, 16} & set(header.values())
+    assert header["OPT_EXCHANGE_SCHEDULE"] == 19 and header["OPT_SOR_FOLD"] == 22
+
+
 def test_version_and_error_reporting_without_gpu(sfl):
     lib = sfl.capi.lib()
     assert lib.sfl_abi_version() == 1
