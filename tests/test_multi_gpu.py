@@ -147,3 +147,27 @@ def test_a_real_time_out_is_an_error_line_of_the_experiment_and_the_headline_sta
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["exchange_mode"] == "library default" and out["fallback_from"] == [] and out["parity"]["bit_exact"]
     assert "a wait inside a solve lasted longer than" in out["in_time_experiment"]["failed"], out["in_time_experiment"]
+
+
+def test_the_drivers_own_command_line_on_a_shared_device():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` -- how the driver starts a multi-GPU run:
+    every process torch.distributed.run starts is its rank's SUPERVISOR (it never touches a GPU) and starts fresh workers per attempt;
+    with real RCCL rank processes on one device: ONE JSON line, the headline from the library's own schedule, the in-time experiment
+    beside it with the same pressure, parity of the solve and of the sim step."""
+    if _devices() < 1:
+        pytest.skip("needs a GPU")
+    _needs_loopback()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "2048", "--iters", "40", "--steps", "6",
+           "--warmup", "1", "--sim-steps", "1", "--no-priming", "--share-device", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SFL_BENCH_WORKER")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["exchange_mode"] == "library default" and out["fallback_from"] == []
+    assert out["config"]["exchange_schedule"] == "one launch early, behind events"
+    assert out["parity"]["bit_exact"] and out["sim_step_parity"]["bit_exact"] is True
+    exp = out["in_time_experiment"]
+    assert exp.get("pressure_matches_headline_bit_for_bit") is True and exp["exchange_schedule"] == "in time, counted on the device", exp
