@@ -256,16 +256,15 @@ int halo_timeout_us(const sfl_context *c)
 
 // ---- poisson_solve executor --------------------------------------------------------------
 // One SOR launch of a plan step over output rows [g_begin, g_end) (a step may be issued in pieces:
-// all pieces read c->p and write c->p_alt; the caller swaps once per step).
-// `in` / `out` = the step's input and output arrays (null: c->p / c->p_alt); `on` = stream (null: the compute stream)
+// all pieces read c->p and write c->p_alt; the caller swaps once per step).  `on` = stream (null: the compute stream)
 int launch_sor_rows(sfl_context *c, const sfl_plan_step &st, const sfl::SorParams &prm, int g_begin, int g_end,
-                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const float *in = nullptr,
-                    float *out = nullptr, const sfl::HaloWait *wait = nullptr, int *senders = nullptr)
+                    int g2_begin = 0, int g2_end = 0, hipStream_t on = nullptr, const sfl::HaloWait *wait = nullptr,
+                    int *senders = nullptr)
 {
     if (senders) *senders = 0;
     if (g_end <= g_begin && g2_end <= g2_begin) return SFL_OK;
-    if (!in) in = c->p;
-    if (!out) out = c->p_alt;
+    const float *in = c->p;
+    float *out = c->p_alt;
     SFL_TRY(use_device(c));
     // Slabs that outgrow the Infinity Cache (256 MB; p + d of 48 M cells = 384 MB) reverse the stream direction of
     // every tile from one launch to the next: a launch then begins on the rows its predecessor read and wrote
@@ -349,7 +348,7 @@ int run_poisson_in_time(sfl_context *ctx, const std::vector<sfl_context *> &peer
                 w.send_hi_begin = c->rank < c->nranks - 1 ? c->g1 - x.g_begin - x.rows : (1 << 30);
             }
             int senders = 0;
-            SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr, nullptr, nullptr,
+            SFL_TRY(launch_sor_rows(c, st, prm, st.g_begin, st.g_end, 0, 0, nullptr,
                                     (flagged || sends) ? &w : nullptr, &senders));
             c->done_target += senders;
             std::swap(c->p, c->p_alt);
