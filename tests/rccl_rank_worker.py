@@ -257,10 +257,52 @@ def scenario_late_peer():
     return 0 if all(verdicts) else 1
 
 
+def scenario_quiescent():
+    """The sketch's own scenario (ino:199, 249-289) between REAL RCCL rank processes: velocity zero, a handful of drag messages queued
+    on every rank (sfl_queue_drags), two whole sim steps at 80 SOR iterations -- the pressure front decays through the denormals, the
+    projected velocity carries them into the second step -- in every exchange schedule; velocity, divergence, pressure and dye of this
+    rank's rows bit for bit against the oracle."""
+    dim_x, dim_y, iters, steps = 640, 288 * world, 80, 2
+    rng = np.random.default_rng(seed)
+    v = np.zeros((dim_y, dim_x, 2), np.float32)
+    c = rng.integers(0, 2 ** 31, (dim_y, dim_x, 3), dtype=np.uint32)
+    cut = dim_y // world
+    drags = [(cut - 1, 300, 35.0, -20.0), (cut, 301, 30.0, -25.0), (dim_y // 2 + 17, 90, -60.0, 12.0), (dim_y - 1, dim_x - 1, 5.0, 5.0)]
+    forces = ([(y, x) for x, y, _, _ in drags], [(vy, vx) for _, _, vx, vy in drags])      # cells (i, j), velocities: the swap of ino:264-269
+    dt, omega = np.float32(1 / 30.0), np.float32(1.96)
+    vo, co = v, c
+    for k in range(steps):
+        va = orc.advect_vec2f(vo, vo, dt, True)
+        if k == 0:
+            for (i, j), u in zip(*forces):
+                va[j, i] = u
+        do = orc.divergence(va, 1.0)
+        po = orc.poisson_solve(do, 1.0, iters, omega)
+        vo = orc.subtract_gradient(va, po, 1.0)
+        co = orc.advect_vec3uq32(co, vo, dt, False)
+    front = int(np.count_nonzero((po != 0) & (np.abs(po) < np.float32(2.0 ** -124))))
+    ok = front > 50          # (the scenario must reach the denormal range)
+    for sched in ("by-event", "in-time", "in-line"):
+        with sfl.Solver(dim_x, dim_y, device=0, rank=rank, nranks=world) as s:
+            for k, val in SCHEDULES[sched].items():
+                s.set_option(k, val)
+            attach(s)
+            s.upload(capi.FIELD_VELOCITY, slab(s, v))
+            s.upload(capi.FIELD_COLOR, slab(s, c))
+            s.queue_drags(drags)
+            s.step_n(steps, dt, 1.0, iters, omega)
+            s.synchronize()
+            ok = ok and same(s, capi.FIELD_VELOCITY, vo) and same(s, capi.FIELD_DIVERGENCE, do) and \
+                same(s, capi.FIELD_PRESSURE, po) and same(s, capi.FIELD_COLOR, co)
+    verdicts = everyone(ok)
+    print(json.dumps({"rank": rank, "ok": all(verdicts), "mine": ok, "denormal_front_cells": front}), flush=True)
+    return 0 if all(verdicts) else 1
+
+
 if __name__ == "__main__":
     try:
         code = {"soak": scenario_soak, "mismatch": scenario_mismatch, "gather": scenario_gather, "forces": scenario_forces,
-                "late_peer": scenario_late_peer}[scenario]()
+                "late_peer": scenario_late_peer, "quiescent": scenario_quiescent}[scenario]()
     finally:
         rdzv.close()
     sys.exit(code)

@@ -74,3 +74,10 @@ def test_forces_on_both_sides_of_a_cut_between_processes(world):
 def test_in_time_exchanges_with_a_peer_that_is_late_to_every_solve():
     results = run_ranks(3, "late_peer", 5)
     assert all(r["schedule"] == 3 and r["exchanges"] > 1 for r in results), results
+
+
+def test_quiescent_field_with_drags_between_processes():
+    """The input class of round 6 (a quiescent field, sparse forcing, 80 iterations, two whole sim steps) on three real RCCL rank
+    processes, every exchange schedule: all four fields of every rank bit for bit; the scenario is checked to reach the denormals."""
+    results = run_ranks(3, "quiescent", 21)
+    assert all(r["denormal_front_cells"] > 50 for r in results), results
