@@ -454,7 +454,10 @@ class Attempts:
             return None
         if self.experiment is None:
             return self.headline
-        d = json.loads(self.headline)
+        try:
+            d = json.loads(self.headline)
+        except ValueError:      # (a line that is not JSON is still the run's line: never lose the headline to the experiment)
+            return self.headline
         d["in_time_experiment"] = self.experiment
         return json.dumps(d)
 
